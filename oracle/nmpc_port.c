@@ -1,0 +1,959 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- see nmpc_port.h.
+ *
+ * Scalar fp64 restatement of the reference NMPC hot path.  Every arithmetic
+ * expression keeps the operand order, association and float-rounded literals
+ * of the reference so that results are bit-identical to the reference compiled
+ * without FMA contraction (build with -ffp-contract=off, no -ffast-math).
+ *
+ * Reference locations (paths relative to the reference tree):
+ *   model        ccs-c66x/cnmpc.c:168-280 (quaternion helpers, fatan2),
+ *                :320-363 (kinematics), :365-400 (RK4), :402-539 (X8 aero),
+ *                :541-579 (state difference), :583-667 (stage linearisation)
+ *   controller   ccs-c66x/cnmpc.c:675-726, :872-1086
+ *   QP solver    ccs-c66x/qpDUNES/dual_qp.c, setup_qp.c,
+ *                stage_qp_solver_clipping.c, matrix_vector.c, utils.c
+ *                (qpDUNES 1.0beta, vendored in the reference)
+ */
+#include "nmpc_port.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+enum { NS = 13, NU = 3, NX = 12, NZ = 15, NREF = 16 };
+
+/* qpDUNES return codes used on this path (qpDUNES/types.h:211-231) */
+enum {
+    ST_OK = 0,
+    ST_OPTIMAL = 1,
+    ST_ITER_LIMIT = 8,
+    ST_DIV_ZERO = 9,
+    ST_LS_MAXITER = 10,
+    ST_LS_MIN_STEP = 11,
+    ST_LS_MAX_STEP = 12,
+    ST_NO_ASCENT = 13
+};
+
+/* effective solver options: setup_qp.c:667-725 overridden at cnmpc.c:891-894 */
+#define OPT_MAX_ITER 5
+#define OPT_MAX_LS_ITER 19
+#define OPT_MAX_LS_REFINE 40
+#define OPT_STAT_TOL ((double)1e-3f)
+#define OPT_EQ_TOL 2.221e-16
+#define OPT_DIAG_REG_TOL 1.e-10
+#define OPT_ACT_TOL (1e4 * 2.221e-16)
+#define OPT_INFTY 1.e12
+#define OPT_REG_PARAM 1.e-6
+#define OPT_LS_REDUCTION 0.1
+#define OPT_LS_INCREASE 1.5
+#define OPT_LS_MIN_ABS 2.221e-16
+#define OPT_LS_MIN_REL 1.e-14
+#define OPT_LS_STAT_TOL 1.e-3
+#define OPT_LS_MAX_STEP 1.
+
+#define FD_STEP 1.221e-4            /* cnmpc.c:154 */
+#define STEP_LENGTH (1.0 / 50.0)    /* include/config.h:60 */
+#define G_ACC 9.80665
+#define RHO_AIR 1.225
+
+typedef struct {
+    double C[NX * NZ], c[NX];
+    double zLow[NZ], zUpp[NZ];
+    double q[NZ], p;
+    double z[NZ], y[2 * NZ];
+    double qStep[NZ], pStep;
+    double zUnc[NZ], dz[NZ];
+    double tmp[NZ];             /* trial vector (zVecTmp) */
+    int nV;
+    int changed;                /* actSetHasChanged */
+} stage_t;
+
+struct port_s {
+    int N;
+    double wind[3];
+    double *xref;               /* (N+1) x 13 */
+    double *uref;               /* N x 3 */
+    double lb[NU], ub[NU], wq[NX], wr[NU], wt[NX];
+    double Hreg[NZ], Hterm[NX]; /* stage Hessian diagonals as the solver sees them */
+    stage_t *rec;               /* N+1 records */
+    int *slot;                  /* position -> record */
+    double *lambda, *dlambda, *grad, *gradTry, *hess, *chol;
+    int *ieq, *prev;            /* (N+1) x 15 */
+    double alpha;
+    int numIter, lastResult, lastStatus, lsIter, regularized;
+    double u[NU];
+};
+
+/* ------------------------------------------------------------------ model */
+
+static void quat_mul(double *r, const double *a, const double *b) {
+    /* xyzw storage, cnmpc.c:175-178 */
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    r[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+}
+
+static void quat_rotate(double *r, const double *q, const double *v) {
+    /* cnmpc.c:213-239 */
+    double tx, ty, tz, rx, ry, rz;
+    tx = q[1] * v[2];
+    ty = q[2] * v[0];
+    tx -= q[2] * v[1];
+    ty -= q[0] * v[2];
+    tz = q[0] * v[1];
+    ty *= 2.0;
+    tz -= q[1] * v[0];
+    tx *= 2.0;
+    tz *= 2.0;
+    rx = v[0]; rx += q[3] * tx; rx += q[1] * tz; rx -= q[2] * ty;
+    ry = v[1]; ry += q[3] * ty; ry += q[2] * tx; ry -= q[0] * tz;
+    rz = v[2]; rz += q[3] * tz; rz -= q[1] * tx; rz += q[0] * ty;
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+static float approx_atan2(float y, float x) {
+    /* cnmpc.c:257-280: float in, float out, mixed float/double inside */
+    const double pi = 3.14159265, pi_2 = 1.5707963;
+    if (x == 0.0) {
+        if (y > 0.0) return (float)pi_2;
+        if (y == 0.0) return 0.0f;
+        return (float)-pi_2;
+    }
+    float res;
+    float z = y / x;
+    if ((z < 0 ? -z : z) < 1.0) {
+        res = (float)(z / (1.0 + 0.28 * z * z));
+        if (x < 0.0) {
+            if (y < 0.0) return (float)(res - pi);
+            return (float)(res + pi);
+        }
+    } else {
+        res = (float)(pi_2 - z / (z * z + 0.28));
+        if (y < 0.0) return (float)(res - pi);
+    }
+    return res;
+}
+
+#define FMAXM(a, b) (((a) > (b)) ? (a) : (b))
+#define FABSM(x) ((x) < 0 ? -(x) : (x))
+
+void port_x8_dynamics(double *out, const double *s, const double *u,
+                      const double *wind) {
+    /* cnmpc.c:402-539 */
+    double ned[3], af[3];
+    ned[0] = wind[0] - s[3];
+    ned[1] = wind[1] - s[4];
+    ned[2] = wind[2] - s[5];
+    quat_rotate(af, &s[6], ned);
+
+    double rx, ry, rz, tx, ty;
+    tx = s[7] * (G_ACC * 2.0f);
+    ty = -s[6] * (G_ACC * 2.0f);
+    rx = s[9] * tx;
+    ry = s[9] * ty;
+    ry += s[8] * tx;
+    rx -= s[8] * ty;
+    rz = G_ACC;
+    rz -= s[7] * tx;
+    rz += s[6] * ty;
+    out[0] = rx; out[1] = ry; out[2] = rz;
+
+    double ax2 = af[0] * af[0], ay2 = af[1] * af[1], az2 = af[2] * af[2];
+    double rpm = u[0] * 25000.0f;
+    double ve2 = (0.0025f * 0.0025f) * rpm * rpm;
+    double thrust = FMAXM(0.0f, ve2 - ax2) *
+                    (0.26315789473684f * 0.5f * RHO_AIR * 0.025f);
+
+    double hv2 = ax2 + ay2;
+    double qbar = (RHO_AIR * 0.5f) * hv2;
+    double v_inv = (double)(1.0 / sqrt(FMAXM(1.0f, hv2 + az2)));
+    double vv = (double)sqrt(ax2 + az2);
+    double vv_inv = (double)(1.0 / (FMAXM(1.0f, vv)));
+
+    double sin_b = af[1] * v_inv;
+    double cos_b = vv * v_inv;
+    double alpha = approx_atan2((float)-af[2], (float)-af[0]);
+    double a2 = alpha * alpha;
+    double sin_a = -af[2] * vv_inv;
+    double cos_a = -af[0] * vv_inv;
+
+    double lift = (-5.0f * alpha + 1.0f) * a2 + 2.5f * alpha + 0.12f;
+    double sca = sin_a * cos_a;
+    double alt = 0.8f * sca;
+    if ((alpha < -0.25f && lift > alt) || (alpha > 0.0f && lift < alt))
+        lift = alt;
+
+    lift = (qbar * 0.26315789473684f) * lift;
+    double drag = (qbar * 0.26315789473684f) * (0.05f + 0.7f * sin_a * sin_a);
+    double side = (qbar * 0.26315789473684f) * 0.3f * sin_b * cos_b;
+
+    double fx = lift * sin_a - drag * cos_a - side * sin_b;
+    double fz = lift * cos_a + drag * sin_a;
+    double fy = side * cos_b;
+    out[1] += fy;
+    out[0] += fx + thrust;
+    out[2] -= fz;
+
+    double yaw_r = s[12], pitch_r = s[11], roll_r = s[10];
+    double la = u[1] - 0.5f, ra = u[2] - 0.5f;
+    double pm = 0.001f - 0.1f * sca - 0.003f * pitch_r - 0.04f * (la + ra);
+    double rm = 0.03f * sin_b - 0.015f * roll_r + 0.1f * (la - ra);
+    double ym = -0.02f * sin_b - 0.05f * yaw_r - 0.01f * (FABSM(la) + FABSM(ra));
+    pm *= qbar; rm *= qbar; ym *= qbar;
+
+    out[4] = 5.8823528f * pm;
+    out[3] = (3.364222f * rm + 0.27744448f * ym);
+    out[5] = (0.27744448f * rm + 2.4920163f * ym);
+}
+
+void port_state_model(double *out, const double *s, const double *u,
+                      const double *wind) {
+    /* cnmpc.c:320-363 */
+    double acc[6], a[4], w[4];
+    port_x8_dynamics(acc, s, u, wind);
+    out[0] = s[3]; out[1] = s[4]; out[2] = s[5];
+    a[0] = s[6]; a[1] = s[7]; a[2] = s[8]; a[3] = -s[9];
+    quat_rotate(&out[3], a, acc);
+    a[3] = -a[3];
+    w[0] = -s[10]; w[1] = -s[11]; w[2] = -s[12]; w[3] = 0.0;
+    quat_mul(&out[6], w, a);
+    out[6] *= 0.5; out[7] *= 0.5; out[8] *= 0.5; out[9] *= 0.5;
+    out[10] = acc[3]; out[11] = acc[4]; out[12] = acc[5];
+}
+
+static void axpy13(double *r, const double *d, double a, const double *s) {
+    for (int i = 0; i < NS; i++) r[i] = s[i] + d[i] * a;
+}
+
+void port_rk4(double *out, const double *s, const double *u, const double *wind,
+              double delta) {
+    /* cnmpc.c:365-400 */
+    double a[NS], b[NS], c[NS], d[NS], t[NS];
+    port_state_model(a, s, u, wind);
+    axpy13(t, a, delta * 0.5f, s);
+    port_state_model(b, t, u, wind);
+    axpy13(t, b, delta * 0.5f, s);
+    port_state_model(c, t, u, wind);
+    axpy13(t, c, delta, s);
+    port_state_model(d, t, u, wind);
+    double d3 = delta * (1.0f / 3.0f), d6 = delta * (1.0f / 6.0f);
+    for (int i = 0; i < NS; i++)
+        out[i] = s[i] + d3 * (b[i] + c[i]) + d6 * (a[i] + d[i]);
+}
+
+void port_state_to_delta(double *dl, const double *s1, const double *s2) {
+    /* cnmpc.c:541-579 */
+    for (int i = 0; i < 3; i++) {
+        dl[i] = s2[i] - s1[i];
+        dl[i + 3] = s2[i + 3] - s1[i + 3];
+        dl[i + 9] = s2[i + 10] - s1[i + 10];
+    }
+    double cj[4], e[4];
+    cj[0] = s1[6]; cj[1] = s1[7]; cj[2] = s1[8]; cj[3] = -s1[9];
+    quat_mul(e, &s2[6], cj);
+    if (e[3] < 0) { e[0] = -e[0]; e[1] = -e[1]; e[2] = -e[2]; e[3] = -e[3]; }
+    double d = 4.0 / (1.0 + e[3]);
+    dl[6] = e[0] * d; dl[7] = e[1] * d; dl[8] = e[2] * d;
+}
+
+void port_linearise(const double *x, const double *u, const double *xnext,
+                    const double *wind, const double *lower,
+                    const double *upper, double *jac, double *res) {
+    /* cnmpc.c:583-667 */
+    double nominal[NS], moved[NS], col[NX];
+    port_rk4(nominal, x, u, wind, STEP_LENGTH);
+    port_state_to_delta(res, xnext, nominal);
+    for (int j = 0; j < NZ; j++) {
+        double pr[NREF];
+        double h = FD_STEP, hinv = (double)(1.0 / FD_STEP);
+        for (int i = 0; i < NS; i++) pr[i] = x[i];
+        pr[13] = u[0]; pr[14] = u[1]; pr[15] = u[2];
+        if (j < 6) {
+            pr[j] += FD_STEP;
+        } else if (j <= 8) {
+            double dp[3] = {0.0, 0.0, 0.0}, dq[4], t[4];
+            dp[j - 6] = FD_STEP;
+            dq[3] = -(FD_STEP * FD_STEP) + 16.0 / (16.0 + FD_STEP * FD_STEP);
+            dq[0] = (1.0 / 4.0) * (1.0 + dq[3]) * dp[0];
+            dq[1] = (1.0 / 4.0) * (1.0 + dq[3]) * dp[1];
+            dq[2] = (1.0 / 4.0) * (1.0 + dq[3]) * dp[2];
+            quat_mul(t, dq, &pr[6]);
+            pr[6] = t[0]; pr[7] = t[1]; pr[8] = t[2]; pr[9] = t[3];
+        } else if (j < NX) {
+            pr[j + 1] += FD_STEP;
+        } else {
+            h *= (upper[j - NX] - lower[j - NX]);
+            hinv = 1.0 / h;
+            pr[j + 1] += h;
+        }
+        port_rk4(moved, pr, &pr[13], wind, STEP_LENGTH);
+        port_state_to_delta(col, nominal, moved);
+        for (int r = 0; r < NX; r++) jac[NZ * r + j] = col[r] * hinv;
+    }
+}
+
+/* ------------------------------------------------------------- lifecycle */
+
+port_t *port_create(int horizon) {
+    port_t *p = calloc(1, sizeof(*p));
+    int N = horizon;
+    p->N = N;
+    p->xref = calloc((size_t)(N + 1) * NS, sizeof(double));
+    p->uref = calloc((size_t)N * NU, sizeof(double));
+    p->rec = calloc((size_t)N + 1, sizeof(stage_t));
+    p->slot = calloc((size_t)N + 1, sizeof(int));
+    p->lambda = calloc((size_t)N * NX, sizeof(double));
+    p->dlambda = calloc((size_t)N * NX, sizeof(double));
+    p->grad = calloc((size_t)N * NX, sizeof(double));
+    p->gradTry = calloc((size_t)N * NX, sizeof(double));
+    p->hess = calloc((size_t)N * 2 * NX * NX, sizeof(double));
+    p->chol = calloc((size_t)N * 2 * NX * NX, sizeof(double));
+    p->ieq = calloc((size_t)(N + 1) * NZ, sizeof(int));
+    p->prev = calloc((size_t)(N + 1) * NZ, sizeof(int));
+    for (int k = 0; k <= N; k++) p->slot[k] = k;
+    return p;
+}
+
+void port_destroy(port_t *p) {
+    if (!p) return;
+    free(p->xref); free(p->uref); free(p->rec); free(p->slot);
+    free(p->lambda); free(p->dlambda); free(p->grad); free(p->gradTry);
+    free(p->hess); free(p->chol); free(p->ieq); free(p->prev);
+    free(p);
+}
+
+void port_set_state_weights(port_t *p, const double *w) { memcpy(p->wq, w, sizeof p->wq); }
+void port_set_control_weights(port_t *p, const double *w) { memcpy(p->wr, w, sizeof p->wr); }
+void port_set_terminal_weights(port_t *p, const double *w) { memcpy(p->wt, w, sizeof p->wt); }
+void port_set_lower_control_bound(port_t *p, const double *b) { memcpy(p->lb, b, sizeof p->lb); }
+void port_set_upper_control_bound(port_t *p, const double *b) { memcpy(p->ub, b, sizeof p->ub); }
+void port_set_wind_velocity(port_t *p, double x, double y, double z) {
+    p->wind[0] = x; p->wind[1] = y; p->wind[2] = z;
+}
+
+static stage_t *stage_at(const port_t *p, int k) { return &p->rec[p->slot[k]]; }
+static const double *stage_H(const port_t *p, int k) {
+    return (k < p->N) ? p->Hreg : p->Hterm;
+}
+
+static void mark_data_changed(port_t *p) {
+    /* setup_qp.c:39-50 */
+    for (int i = 0; i < (p->N + 1) * NZ; i++) p->prev[i] = -42;
+}
+
+/* A diagonal weight block that is the identity to within 1e-15 carries no
+ * data in the solver and behaves as exact ones (utils.c:106-117,
+ * setup_qp.c:229-258). */
+static int is_identity(const double *w, int n) {
+    for (int i = 0; i < n; i++)
+        if (fabs(w[i] - 1.0) > 1e-15) return 0;
+    return 1;
+}
+
+/* setup_qp.c:547-585 for the clipping solver with a diagonal Hessian.
+ * The stage's linear term g is identically zero in this controller. */
+static void restage(port_t *p, int k) {
+    stage_t *s = stage_at(p, k);
+    const double *H = stage_H(p, k);
+    int nV = s->nV, N = p->N;
+    for (int i = 0; i < nV; i++) s->q[i] = 0.0;
+    if (k < N) {
+        const double *l1 = &p->lambda[k * NX];
+        for (int j = 0; j < NZ; j++) s->qStep[j] = 0.;
+        for (int i = 0; i < NX; i++)
+            for (int j = 0; j < NZ; j++) s->qStep[j] += s->C[i * NZ + j] * l1[i];
+        double ps = 0.;
+        for (int i = 0; i < NX; i++) ps += l1[i] * s->c[i];
+        s->pStep = ps;
+    } else {
+        for (int j = 0; j < nV; j++) s->qStep[j] = 0.0;
+        s->pStep = 0.;
+    }
+    if (k > 0) {
+        const double *l0 = &p->lambda[(k - 1) * NX];
+        for (int i = 0; i < NX; i++) s->qStep[i] -= l0[i];
+    }
+    for (int i = 0; i < nV; i++) s->qStep[i] += 0.0;       /* + g */
+    for (int i = 0; i < nV; i++) s->dz[i] = s->qStep[i] / H[i];
+    for (int i = 0; i < nV; i++) s->dz[i] = -s->dz[i];
+    for (int i = 0; i < nV; i++) s->zUnc[i] = 0.0;
+}
+
+void port_init(port_t *p) {
+    /* cnmpc.c:872-948 */
+    int N = p->N;
+    for (int k = 0; k <= N; k++) {
+        p->slot[k] = k;
+        p->rec[k].nV = (k < N) ? NZ : NX;
+    }
+    mark_data_changed(p);
+
+    int idq = is_identity(p->wq, NX), idr = is_identity(p->wr, NU);
+    for (int i = 0; i < NX; i++) p->Hreg[i] = idq ? 1. : p->wq[i];
+    for (int i = 0; i < NU; i++) p->Hreg[NX + i] = idr ? 1. : p->wr[i];
+    int idt = is_identity(p->wt, NX);
+    for (int i = 0; i < NX; i++) p->Hterm[i] = idt ? 1. : p->wt[i];
+
+    for (int k = 0; k < N; k++) {
+        stage_t *s = stage_at(p, k);
+        memset(s->C, 0, sizeof s->C);
+        memset(s->c, 0, sizeof s->c);
+        for (int i = 0; i < NX; i++) { s->zLow[i] = -OPT_INFTY; s->zUpp[i] = OPT_INFTY; }
+        for (int i = 0; i < NU; i++) { s->zLow[NX + i] = p->lb[i]; s->zUpp[NX + i] = p->ub[i]; }
+    }
+    stage_t *t = stage_at(p, N);
+    for (int i = 0; i < NX; i++) { t->zLow[i] = -OPT_INFTY; t->zUpp[i] = OPT_INFTY; }
+
+    for (int k = 0; k <= N; k++) restage(p, k);
+    mark_data_changed(p);
+}
+
+void port_set_reference_point(port_t *p, const double *ref, unsigned i) {
+    /* cnmpc.c:1022-1080 */
+    memcpy(&p->xref[i * NS], ref, NS * sizeof(double));
+    if (i > 0 && i <= (unsigned)p->N) {
+        int k = (int)i - 1;
+        double *ur = &p->uref[k * NU];
+        stage_t *s = stage_at(p, k);
+        memcpy(ur, &ref[NS], NU * sizeof(double));
+        for (int j = 0; j < NX; j++) { s->zLow[j] = -OPT_INFTY; s->zUpp[j] = OPT_INFTY; }
+        for (int j = 0; j < NU; j++) {
+            s->zLow[NX + j] = p->lb[j] - ur[j];
+            s->zUpp[NX + j] = p->ub[j] - ur[j];
+        }
+        port_linearise(&p->xref[k * NS], ur, ref, p->wind, p->lb, p->ub, s->C, s->c);
+        restage(p, k);
+    }
+}
+
+/* ------------------------------------------------------- stage QP (clipping) */
+
+static void clip_to_bounds(double *v, double *y, const double *lo,
+                           const double *up, int n) {
+    /* stage_qp_solver_clipping.c:174-198 */
+    for (int i = 0; i < n; i++) {
+        y[2 * i] = lo[i] - v[i];
+        y[2 * i + 1] = v[i] - up[i];
+        if (y[2 * i] >= -OPT_ACT_TOL) v[i] = lo[i];
+        else if (y[2 * i + 1] >= -OPT_ACT_TOL) v[i] = up[i];
+    }
+}
+
+/* Commit a step of length a (stage_qp_solver_clipping.c:134-165). */
+static void stage_step(stage_t *s, double a) {
+    int n = s->nV;
+    for (int i = 0; i < n; i++) s->zUnc[i] = s->zUnc[i] + a * s->dz[i];
+    for (int i = 0; i < n; i++) s->z[i] = s->zUnc[i];
+    clip_to_bounds(s->z, s->y, s->zLow, s->zUpp, n);
+    for (int i = 0; i < n; i++) s->q[i] = s->q[i] + a * s->qStep[i];
+    s->p = s->p + a * s->pStep;
+}
+
+static double stage_objective(const double *H, const double *z, const double *q,
+                              double p, int n) {
+    double zHz = 0., qz = 0.;
+    for (int j = 0; j < n; j++) zHz += H[j] * z[j] * z[j];
+    double v = 0.5 * zHz;
+    for (int j = 0; j < n; j++) qz += q[j] * z[j];
+    v += qz;
+    v += p;
+    return v;
+}
+
+static double objective(port_t *p) {
+    /* dual_qp.c:1542-1566 */
+    double obj = 0.;
+    for (int k = 0; k <= p->N; k++) {
+        stage_t *s = stage_at(p, k);
+        obj += stage_objective(stage_H(p, k), s->z, s->q, s->p, s->nV);
+    }
+    return obj;
+}
+
+/* dual_qp.c:1574-1617: trial step; overwrites z and y, leaves zUnc, q, p. */
+static double trial_objective(port_t *p, double a) {
+    double obj = 0.;
+    for (int k = 0; k <= p->N; k++) {
+        stage_t *s = stage_at(p, k);
+        int n = s->nV;
+        for (int i = 0; i < n; i++) s->z[i] = s->zUnc[i] + a * s->dz[i];
+        clip_to_bounds(s->z, s->y, s->zLow, s->zUpp, n);
+        for (int i = 0; i < n; i++) s->tmp[i] = s->q[i] + a * s->qStep[i];
+        double pt = s->p + a * s->pStep;
+        obj += stage_objective(stage_H(p, k), s->z, s->tmp, pt, n);
+    }
+    return obj;
+}
+
+static void active_set(port_t *p) {
+    /* dual_qp.c:1627-1668 */
+    for (int k = 0; k <= p->N; k++) {
+        stage_t *s = stage_at(p, k);
+        for (int i = 0; i < s->nV; i++) {
+            int v;
+            if (s->y[2 * i] > OPT_EQ_TOL) v = -1;
+            else if (s->y[2 * i + 1] > OPT_EQ_TOL) v = 1;
+            else v = 0;
+            p->ieq[k * NZ + i] = v;
+        }
+    }
+}
+
+static int compare_active_sets(port_t *p) {
+    /* dual_qp.c:1677-1699; returns the last stage whose set changed or -1 */
+    int last = -1;
+    for (int k = 0; k <= p->N; k++) {
+        stage_t *s = stage_at(p, k);
+        s->changed = 0;
+        for (int i = 0; i < s->nV; i++)
+            if (p->ieq[k * NZ + i] != p->prev[k * NZ + i]) { s->changed = 1; last = k; }
+    }
+    return last;
+}
+
+/* ---------------------------------------------------------- Newton system */
+
+#define HS(M, k, l, i, j) (M)[(k) * 2 * NX * NX + (i) * 2 * NX + (1 + (l)) * NX + (j)]
+
+static void stage_gradient(double *g, const stage_t *s, const double *zk,
+                           const double *znext) {
+    for (int i = 0; i < NX; i++) {
+        double a = 0.;
+        for (int j = 0; j < NZ; j++) a += s->C[i * NZ + j] * zk[j];
+        g[i] = a;
+    }
+    for (int i = 0; i < NX; i++) g[i] += s->c[i];
+    for (int i = 0; i < NX; i++) g[i] -= znext[i];
+}
+
+static double norm2(const double *v, int n) {
+    double r = 0.;
+    for (int i = 0; i < n; i++) r += v[i] * v[i];
+    return sqrt(r);
+}
+
+static int setup_newton(port_t *p) {
+    /* dual_qp.c:423-566 */
+    int N = p->N;
+    for (int k = 0; k < N; k++)
+        stage_gradient(&p->grad[k * NX], stage_at(p, k), stage_at(p, k)->z,
+                       stage_at(p, k + 1)->z);
+    if (norm2(p->grad, NX * N) < OPT_STAT_TOL) return ST_OPTIMAL;
+
+    double M[NX * NX], Zt[NZ * NX];
+    for (int k = 0; k < N; k++) {
+        stage_t *s = stage_at(p, k), *sn = stage_at(p, k + 1);
+        if (!(s->changed || sn->changed)) continue;
+        const double *Hn = stage_H(p, k + 1), *H = stage_H(p, k);
+        for (int i = 0; i < NX * NX; i++) M[i] = 0.;
+        for (int i = 0; i < NX; i++) {
+            M[i * NX + i] = 1. / Hn[i];
+            if (sn->y[2 * i] >= OPT_EQ_TOL || sn->y[2 * i + 1] >= OPT_EQ_TOL)
+                M[i * NX + i] = 0.;
+        }
+        for (int l = 0; l < NZ; l++)
+            for (int j = 0; j < NX; j++) Zt[l * NX + j] = s->C[j * NZ + l] / H[l];
+        for (int l = 0; l < NZ; l++) {
+            if (s->y[2 * l] <= OPT_EQ_TOL && s->y[2 * l + 1] <= OPT_EQ_TOL)
+                for (int i = 0; i < NX; i++)
+                    for (int j = 0; j < NX; j++)
+                        M[i * NX + j] += s->C[i * NZ + l] * Zt[l * NX + j];
+        }
+        for (int i = 0; i < NX; i++)
+            for (int j = 0; j < NX; j++) HS(p->hess, k, 0, i, j) = M[i * NX + j];
+    }
+    for (int k = 1; k < N; k++) {
+        stage_t *s = stage_at(p, k);
+        if (!s->changed) continue;
+        const double *H = stage_H(p, k);
+        for (int i = 0; i < NX; i++)
+            for (int j = 0; j < NX; j++) {
+                double v = s->C[i * NZ + j] / H[j];
+                if (s->y[2 * j] <= OPT_EQ_TOL && s->y[2 * j + 1] <= OPT_EQ_TOL)
+                    HS(p->hess, k, -1, i, j) = -v;
+                else
+                    HS(p->hess, k, -1, i, j) = 0.;
+            }
+    }
+    return ST_OK;
+}
+
+static int factor_reverse(port_t *p, int last) {
+    /* dual_qp.c:817-908 */
+    int N = p->N;
+    double *L = p->chol;
+    const double *A = p->hess;
+    int start = (last >= 0) ? ((last < N - 1) ? last : N - 1) : -1;
+    for (int k = start; k >= 0; --k) {
+        for (int j = NX - 1; j >= 0; --j) {
+            double sum = HS(A, k, 0, j, j);
+            for (int l = j + 1; l < NX; ++l) sum -= HS(L, k, 0, l, j) * HS(L, k, 0, l, j);
+            if (k < N - 1)
+                for (int l = 0; l < NX; ++l)
+                    sum -= HS(L, k + 1, -1, l, j) * HS(L, k + 1, -1, l, j);
+            if (sum < 1.e2 * OPT_EQ_TOL) return ST_DIV_ZERO;
+            HS(L, k, 0, j, j) = sqrt(sum);
+            for (int i = j - 1; i >= 0; --i) {
+                sum = HS(A, k, 0, j, i);
+                for (int l = j + 1; l < NX; ++l) sum -= HS(L, k, 0, l, i) * HS(L, k, 0, l, j);
+                if (k < N - 1)
+                    for (int l = 0; l < NX; ++l)
+                        sum -= HS(L, k + 1, -1, l, i) * HS(L, k + 1, -1, l, j);
+                HS(L, k, 0, j, i) = sum / HS(L, k, 0, j, j);
+            }
+            if (k > 0)
+                for (int i = NX - 1; i >= 0; --i) {
+                    sum = HS(A, k, -1, j, i);
+                    for (int l = j + 1; l < NX; ++l)
+                        sum -= HS(L, k, -1, l, i) * HS(L, k, 0, l, j);
+                    HS(L, k, -1, j, i) = sum / HS(L, k, 0, j, j);
+                }
+        }
+    }
+    return ST_OK;
+}
+
+static int factor_newton(port_t *p, int last) {
+    /* dual_qp.c:601-698 */
+    int N = p->N;
+    double minDiag = OPT_INFTY;
+    int st = factor_reverse(p, last);
+    if (st == ST_OK)
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < NX; i++)
+                if (minDiag > HS(p->chol, k, 0, i, i)) minDiag = HS(p->chol, k, 0, i, i);
+    if (st == ST_DIV_ZERO || minDiag < OPT_DIAG_REG_TOL) {
+        for (int k = 0; k < N; k++)
+            for (int j = 0; j < NX; j++) HS(p->hess, k, 0, j, j) += OPT_REG_PARAM;
+        p->regularized = 1;
+        st = factor_reverse(p, N + 1);
+        if (st != ST_OK) return st;
+    } else if (st != ST_OK) {
+        return st;
+    }
+    return ST_OK;
+}
+
+static void solve_newton(port_t *p) {
+    /* dual_qp.c:993-1055 */
+    int N = p->N;
+    const double *L = p->chol, *g = p->grad;
+    double *x = p->dlambda;
+    for (int k = N - 1; k >= 0; --k)
+        for (int i = NX - 1; i >= 0; --i) {
+            double sum = g[k * NX + i];
+            for (int j = i + 1; j < NX; ++j) sum -= HS(L, k, 0, j, i) * x[k * NX + j];
+            if (k < N - 1)
+                for (int j = 0; j < NX; ++j) sum -= HS(L, k + 1, -1, j, i) * x[(k + 1) * NX + j];
+            x[k * NX + i] = sum / HS(L, k, 0, i, i);
+        }
+    for (int k = 0; k < N; ++k)
+        for (int i = 0; i < NX; ++i) {
+            double sum = x[k * NX + i];
+            if (k > 0)
+                for (int j = 0; j < NX; ++j) sum -= HS(L, k, -1, i, j) * x[(k - 1) * NX + j];
+            for (int j = 0; j < i; ++j) sum -= HS(L, k, 0, i, j) * x[k * NX + j];
+            x[k * NX + i] = sum / HS(L, k, 0, i, i);
+        }
+}
+
+/* dual_qp.c:309-379 with stage_qp_solver_clipping.c:42-98 */
+static void stage_directions(port_t *p, const double *dl) {
+    int N = p->N;
+    for (int k = 0; k <= N; k++) {
+        stage_t *s = stage_at(p, k);
+        int n = s->nV;
+        if (k < N) {
+            const double *l1 = &dl[k * NX];
+            for (int j = 0; j < NZ; j++) s->qStep[j] = 0.;
+            for (int i = 0; i < NX; i++)
+                for (int j = 0; j < NZ; j++) s->qStep[j] += s->C[i * NZ + j] * l1[i];
+            double ps = 0.;
+            for (int i = 0; i < NX; i++) ps += l1[i] * s->c[i];
+            s->pStep = ps;
+        } else {
+            for (int j = 0; j < n; j++) s->qStep[j] = 0.0;
+            s->pStep = 0.;
+        }
+        if (k > 0) {
+            const double *l0 = &dl[(k - 1) * NX];
+            for (int i = 0; i < NX; i++) s->qStep[i] -= l0[i];
+        }
+    }
+    for (int k = 0; k <= N; k++) {
+        stage_t *s = stage_at(p, k);
+        const double *H = stage_H(p, k);
+        for (int i = 0; i < s->nV; i++) s->dz[i] = s->qStep[i] / H[i];
+        for (int i = 0; i < s->nV; i++) s->dz[i] = -s->dz[i];
+    }
+}
+
+/* -------------------------------------------------------------- line search */
+
+static int backtracking(port_t *p, double *alpha, int *it, double alphaMax,
+                        double objInc) {
+    /* dual_qp.c:1294-1334 with alphaMin = 0 */
+    double minProg = OPT_LS_MIN_REL * fabs(objInc) + OPT_LS_MIN_ABS;
+    double nrm = norm2(p->dlambda, NX * p->N);
+    *alpha = alphaMax;
+    for (; *it < OPT_MAX_LS_ITER; ++(*it)) {
+        double obj = trial_objective(p, *alpha);
+        if (obj > objInc + minProg) return ST_OK;
+        *alpha = (*alpha) * OPT_LS_REDUCTION;
+        if (nrm * (*alpha - 0.) < OPT_EQ_TOL) { *alpha = 0.; return ST_LS_MIN_STEP; }
+    }
+    return ST_LS_MAXITER;
+}
+
+static double trial_slope(port_t *p, double a) {
+    int N = p->N;
+    for (int k = 0; k <= N; k++) {
+        stage_t *s = stage_at(p, k);
+        for (int i = 0; i < s->nV; i++) s->tmp[i] = s->zUnc[i] + a * s->dz[i];
+        clip_to_bounds(s->tmp, s->y, s->zLow, s->zUpp, s->nV);
+    }
+    for (int k = 0; k < N; k++)
+        stage_gradient(&p->gradTry[k * NX], stage_at(p, k), stage_at(p, k)->tmp,
+                       stage_at(p, k + 1)->tmp);
+    double r = 0.;
+    for (int i = 0; i < NX * N; i++) r += p->gradTry[i] * p->dlambda[i];
+    return r;
+}
+
+static int bisection(port_t *p, double *alpha, int *it, double alphaMin,
+                     double alphaMax) {
+    /* dual_qp.c:1341-1470 */
+    double alphaC = 1.0, slope;
+    double nd = norm2(p->dlambda, NX * p->N);
+    double normal = (1. < nd) ? 1. : nd;
+    for (; *it < OPT_MAX_LS_REFINE; ++(*it)) {
+        slope = trial_slope(p, alphaMax);
+        if (fabs(slope / normal) <= OPT_LS_STAT_TOL) { *alpha = alphaMax; return ST_OK; }
+        if (slope / normal < 0.) break;
+        alphaMin = alphaMax;
+        alphaMax *= OPT_LS_INCREASE;
+        if (alphaMax > OPT_LS_MAX_STEP) { *alpha = alphaMin; return ST_LS_MAX_STEP; }
+    }
+    for (; *it < OPT_MAX_LS_REFINE; ++(*it)) {
+        alphaC = 0.5 * (alphaMin + alphaMax);
+        slope = trial_slope(p, alphaC);
+        if (fabs(slope / normal) <= OPT_LS_STAT_TOL) { *alpha = alphaC; return ST_OK; }
+        if (slope > 0) alphaMin = alphaC; else alphaMax = alphaC;
+    }
+    *alpha = alphaC;
+    return ST_LS_MAXITER;
+}
+
+static int step_length(port_t *p, double *objInc) {
+    /* dual_qp.c:1119-1286 */
+    int N = p->N, n = NX * N, st;
+    double alphaMin = OPT_INFTY, alphaMax = 1.;
+    p->lsIter = 0;
+    for (int k = 0; k <= N; k++) {
+        stage_t *s = stage_at(p, k);
+        for (int i = 0; i < s->nV; i++) {
+            double r0 = s->dz[i] / s->y[2 * i], r1 = s->dz[i] / -s->y[2 * i + 1];
+            double a = 1. / ((r0 > r1) ? r0 : r1);
+            if (a > 0. && a < alphaMin) alphaMin = a;
+        }
+    }
+    if (alphaMin > 1. - OPT_EQ_TOL && !p->regularized) {
+        p->alpha = 1.;
+        for (int i = 0; i < n; i++) p->lambda[i] = p->lambda[i] + p->alpha * p->dlambda[i];
+        for (int k = 0; k <= N; k++) stage_step(stage_at(p, k), p->alpha);
+        *objInc = objective(p);
+        return ST_OK;
+    }
+    st = backtracking(p, &p->alpha, &p->lsIter, alphaMax, *objInc);
+    if (st == ST_LS_MIN_STEP) return st;
+    {
+        double cand = p->alpha / OPT_LS_REDUCTION;
+        alphaMax = (alphaMax < cand) ? alphaMax : cand;
+    }
+    st = bisection(p, &p->alpha, &p->lsIter, alphaMin, alphaMax);
+    for (int i = 0; i < n; i++) p->lambda[i] += p->alpha * p->dlambda[i];
+    for (int k = 0; k <= N; k++) stage_step(stage_at(p, k), p->alpha);
+    *objInc = objective(p);
+    return st;
+}
+
+/* ------------------------------------------------------------------ solve */
+
+static int dual_newton_solve(port_t *p) {
+    /* dual_qp.c:39-223 */
+    int N = p->N, last, st;
+    double objInc;
+    p->numIter = 0;
+    for (int k = 0; k <= N; k++) stage_step(stage_at(p, k), 1);
+    objInc = objective(p);
+    active_set(p);
+    last = compare_active_sets(p);
+
+    for (p->numIter = 1; p->numIter <= OPT_MAX_ITER; ++p->numIter) {
+        p->regularized = 0;
+        st = setup_newton(p);
+        if (st != ST_OK) return st;
+        st = factor_newton(p, last);
+        if (st != ST_OK) return st;
+        solve_newton(p);
+        stage_directions(p, p->dlambda);
+        st = step_length(p, &objInc);
+        if (st == ST_LS_MIN_STEP) return ST_NO_ASCENT;
+        memcpy(p->prev, p->ieq, sizeof(int) * (size_t)(N + 1) * NZ);
+        active_set(p);
+        last = compare_active_sets(p);
+    }
+    p->numIter = OPT_MAX_ITER;
+    return ST_ITER_LIMIT;
+}
+
+void port_feedback_step(port_t *p, const double *meas) {
+    /* cnmpc.c:675-726, 953-956 */
+    stage_t *s0 = stage_at(p, 0);
+    double d[NX];
+    port_state_to_delta(d, p->xref, meas);
+    for (int i = 0; i < NX; i++) { s0->zLow[i] = d[i]; s0->zUpp[i] = d[i]; }
+    for (int i = 0; i < NU; i++) {
+        s0->zLow[NX + i] = p->lb[i] - p->uref[i];
+        s0->zUpp[NX + i] = p->ub[i] - p->uref[i];
+    }
+    mark_data_changed(p);
+    p->lastStatus = dual_newton_solve(p);
+    if (p->lastStatus == ST_OPTIMAL) {
+        for (int i = 0; i < NU; i++) p->u[i] = p->uref[i] + s0->z[NX + i];
+        p->lastResult = 1;
+    } else {
+        p->lastResult = 0;
+    }
+}
+
+int port_get_controls(port_t *p, double *u) {
+    memcpy(u, p->u, sizeof p->u);
+    return p->lastResult ? 0 : 1;
+}
+
+void port_update_horizon(port_t *p, const double *ref) {
+    /* cnmpc.c:971-986, setup_qp.c:619-662 */
+    int N = p->N;
+    memmove(p->xref, p->xref + NS, sizeof(double) * NS * (size_t)N);
+    memmove(p->uref, p->uref + NU, sizeof(double) * NU * (size_t)(N - 1));
+    for (int k = 0; k < N - 1; k++)
+        for (int i = 0; i < NX; i++) p->lambda[k * NX + i] = p->lambda[(k + 1) * NX + i];
+    int freed = p->slot[0];
+    for (int k = 0; k < N - 1; k++) p->slot[k] = p->slot[k + 1];
+    p->slot[N - 1] = freed;
+    port_set_reference_point(p, ref, (unsigned)N);
+}
+
+/* ------------------------------------------------------------ introspection */
+
+int port_horizon(const port_t *p) { return p->N; }
+int port_num_iter(const port_t *p) { return p->numIter; }
+int port_last_result(const port_t *p) { return p->lastResult; }
+int port_last_status(const port_t *p) { return p->lastStatus; }
+double port_alpha(const port_t *p) { return p->alpha; }
+int port_line_search_iter(const port_t *p) { return p->lsIter; }
+int port_hessian_regularized(const port_t *p) { return p->regularized; }
+
+void port_get_stage(const port_t *p, unsigned k, double *o) {
+    const stage_t *s = stage_at(p, (int)k);
+    size_t nv = (size_t)s->nV;
+    memset(o, 0, 332 * sizeof(double));
+    if ((int)k < p->N) {
+        memcpy(o, s->C, sizeof s->C);
+        memcpy(o + 180, s->c, sizeof s->c);
+    }
+    memcpy(o + 192, s->zLow, nv * sizeof(double));
+    memcpy(o + 207, s->zUpp, nv * sizeof(double));
+    memcpy(o + 222, s->q, nv * sizeof(double));
+    o[237] = s->p;
+    memcpy(o + 238, s->z, nv * sizeof(double));
+    memcpy(o + 253, s->y, 2 * nv * sizeof(double));
+    memcpy(o + 283, s->qStep, nv * sizeof(double));
+    o[298] = s->pStep;
+    memcpy(o + 299, s->zUnc, nv * sizeof(double));
+    memcpy(o + 314, s->dz, nv * sizeof(double));
+}
+
+unsigned port_global_size(const port_t *p) {
+    unsigned N = (unsigned)p->N;
+    return 3 * 12 * N + 2 * 288 * N + 2 * 15 * (N + 1) + 13 * (N + 1) + 3 * N + 3;
+}
+
+void port_get_global(const port_t *p, double *o) {
+    size_t N = (size_t)p->N;
+    memcpy(o, p->lambda, 12 * N * sizeof(double)); o += 12 * N;
+    memcpy(o, p->dlambda, 12 * N * sizeof(double)); o += 12 * N;
+    memcpy(o, p->grad, 12 * N * sizeof(double)); o += 12 * N;
+    memcpy(o, p->hess, 288 * N * sizeof(double)); o += 288 * N;
+    memcpy(o, p->chol, 288 * N * sizeof(double)); o += 288 * N;
+    for (size_t k = 0; k <= N; k++)
+        for (int i = 0; i < 15; i++)
+            *o++ = (i < stage_at(p, (int)k)->nV) ? (double)p->ieq[k * 15 + i] : 0.0;
+    for (size_t k = 0; k <= N; k++)
+        for (int i = 0; i < 15; i++)
+            *o++ = (i < stage_at(p, (int)k)->nV) ? (double)p->prev[k * 15 + i] : 0.0;
+    memcpy(o, p->xref, 13 * (N + 1) * sizeof(double)); o += 13 * (N + 1);
+    memcpy(o, p->uref, 3 * N * sizeof(double)); o += 3 * N;
+    memcpy(o, p->u, 3 * sizeof(double));
+}
+
+/* ---------------------------------------------------------- batched driver */
+
+typedef struct {
+    int horizon, first, last;
+    const double *wq, *wr, *wt, *lo, *up, *refs, *meas, *wind;
+    double *u;
+    int *status, *iters;
+} job_t;
+
+static void *cold_worker(void *arg) {
+    job_t *j = arg;
+    int N = j->horizon;
+    for (int b = j->first; b < j->last; b++) {
+        port_t *p = port_create(N);
+        port_set_state_weights(p, j->wq);
+        port_set_control_weights(p, j->wr);
+        port_set_terminal_weights(p, j->wt);
+        port_set_lower_control_bound(p, j->lo);
+        port_set_upper_control_bound(p, j->up);
+        port_init(p);
+        const double *w = &j->wind[(size_t)b * 3];
+        port_set_wind_velocity(p, w[0], w[1], w[2]);
+        const double *r = &j->refs[(size_t)b * (size_t)(N + 1) * NREF];
+        for (int i = 0; i <= N; i++) port_set_reference_point(p, &r[i * NREF], (unsigned)i);
+        port_feedback_step(p, &j->meas[(size_t)b * NS]);
+        j->status[b] = port_get_controls(p, &j->u[(size_t)b * 3]);
+        j->iters[b] = p->numIter;
+        port_destroy(p);
+    }
+    return 0;
+}
+
+double port_batch_cold_solve(int horizon, int count, int threads,
+                             const double *wq, const double *wr, const double *wt,
+                             const double *lo, const double *up, const double *refs,
+                             const double *meas, const double *wind, double *u,
+                             int *status, int *iters) {
+    if (threads < 1) threads = 1;
+    if (threads > count) threads = count;
+    pthread_t *tid = calloc((size_t)threads, sizeof(*tid));
+    job_t *jobs = calloc((size_t)threads, sizeof(*jobs));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        job_t j = {horizon, (int)((long)count * t / threads),
+                   (int)((long)count * (t + 1) / threads),
+                   wq, wr, wt, lo, up, refs, meas, wind, u, status, iters};
+        jobs[t] = j;
+        pthread_create(&tid[t], 0, cold_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], 0);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(tid); free(jobs);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,186 @@
+"""Test infrastructure only: ctypes driver for oracle/libnmpc_port.so (the CPU
+restatement of the reference algorithm).  Same surface as refdriver.Ref so the
+two can be run side by side; unlike the reference it is instance-based and the
+horizon is a run-time parameter."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STAGE_REC = 332
+LIB_PATH = os.path.join(HERE, "libnmpc_port.so")
+
+_lib = None
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _f(v, n=None):
+    a = np.ascontiguousarray(v, dtype=np.float64)
+    if n is not None:
+        assert a.size == n, (a.shape, n)
+    return a
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(LIB_PATH + " (run `make -C oracle port`)")
+        L = C.CDLL(LIB_PATH)
+        dp, vp = C.POINTER(C.c_double), C.c_void_p
+        L.port_create.restype = vp
+        L.port_create.argtypes = [C.c_int]
+        L.port_destroy.argtypes = [vp]
+        for n in ("port_set_state_weights", "port_set_control_weights",
+                  "port_set_terminal_weights", "port_set_lower_control_bound",
+                  "port_set_upper_control_bound", "port_feedback_step",
+                  "port_update_horizon", "port_get_global"):
+            getattr(L, n).argtypes = [vp, dp]
+            getattr(L, n).restype = None
+        L.port_get_controls.argtypes = [vp, dp]
+        L.port_set_wind_velocity.argtypes = [vp] + [C.c_double] * 3
+        L.port_set_wind_velocity.restype = None
+        L.port_init.argtypes = [vp]
+        L.port_init.restype = None
+        L.port_set_reference_point.argtypes = [vp, dp, C.c_uint]
+        L.port_set_reference_point.restype = None
+        for n in ("port_horizon", "port_num_iter", "port_last_result",
+                  "port_last_status", "port_line_search_iter",
+                  "port_hessian_regularized"):
+            getattr(L, n).argtypes = [vp]
+        L.port_alpha.argtypes = [vp]
+        L.port_alpha.restype = C.c_double
+        L.port_get_stage.argtypes = [vp, C.c_uint, dp]
+        L.port_global_size.argtypes = [vp]
+        L.port_global_size.restype = C.c_uint
+        L.port_x8_dynamics.argtypes = [dp] * 4
+        L.port_state_model.argtypes = [dp] * 4
+        L.port_rk4.argtypes = [dp] * 4 + [C.c_double]
+        L.port_state_to_delta.argtypes = [dp] * 3
+        L.port_linearise.argtypes = [dp] * 8
+        L.port_batch_cold_solve.restype = C.c_double
+        L.port_batch_cold_solve.argtypes = (
+            [C.c_int] * 3 + [dp] * 8 + [dp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        _lib = L
+    return _lib
+
+
+def have_port():
+    return os.path.exists(LIB_PATH)
+
+
+class Port:
+    def __init__(self, n=100):
+        self.lib = lib()
+        self.N = n
+        self.h = self.lib.port_create(n)
+        from refdriver import global_fields
+        self.gfields, self.gsize = global_fields(n)
+        assert self.lib.port_global_size(self.h) == self.gsize
+
+    def __del__(self):
+        try:
+            self.lib.port_destroy(self.h)
+        except Exception:
+            pass
+
+    def setup(self, state_w, control_w, terminal_w, upper, lower):
+        self.lib.port_set_state_weights(self.h, _dp(_f(state_w, 12)))
+        self.lib.port_set_control_weights(self.h, _dp(_f(control_w, 3)))
+        self.lib.port_set_terminal_weights(self.h, _dp(_f(terminal_w, 12)))
+        self.lib.port_set_lower_control_bound(self.h, _dp(_f(lower, 3)))
+        self.lib.port_set_upper_control_bound(self.h, _dp(_f(upper, 3)))
+
+    def init(self):
+        self.lib.port_init(self.h)
+
+    def set_reference(self, point, i):
+        self.lib.port_set_reference_point(self.h, _dp(_f(point, 16)), i)
+
+    def set_wind(self, w):
+        self.lib.port_set_wind_velocity(self.h, float(w[0]), float(w[1]), float(w[2]))
+
+    def feedback(self, meas):
+        self.lib.port_feedback_step(self.h, _dp(_f(meas, 13)))
+
+    def controls(self):
+        u = np.zeros(3)
+        st = self.lib.port_get_controls(self.h, _dp(u))
+        return u, st
+
+    def update_horizon(self, point):
+        self.lib.port_update_horizon(self.h, _dp(_f(point, 16)))
+
+    def num_iter(self):
+        return self.lib.port_num_iter(self.h)
+
+    def stages(self):
+        out = np.zeros((self.N + 1, STAGE_REC))
+        for k in range(self.N + 1):
+            self.lib.port_get_stage(self.h, k, _dp(out[k]))
+        return out
+
+    def globals_(self):
+        out = np.zeros(self.gsize)
+        self.lib.port_get_global(self.h, _dp(out))
+        return out
+
+    def gfield(self, g, name):
+        o, ln = self.gfields[name]
+        return g[o:o + ln]
+
+
+# -- model functions ------------------------------------------------------
+def x8_dynamics(x, u, wind):
+    out = np.zeros(6)
+    lib().port_x8_dynamics(_dp(out), _dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(wind, 3)))
+    return out
+
+
+def state_model(x, u, wind):
+    out = np.zeros(13)
+    lib().port_state_model(_dp(out), _dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(wind, 3)))
+    return out
+
+
+def rk4(x, u, wind, delta=1.0 / 50.0):
+    out = np.zeros(13)
+    lib().port_rk4(_dp(out), _dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(wind, 3)), delta)
+    return out
+
+
+def state_to_delta(s1, s2):
+    out = np.zeros(12)
+    lib().port_state_to_delta(_dp(out), _dp(_f(s1, 13)), _dp(_f(s2, 13)))
+    return out
+
+
+def linearise(x, u, xnext, wind, lower, upper):
+    jac, res = np.zeros(180), np.zeros(12)
+    lib().port_linearise(_dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(xnext, 13)),
+                         _dp(_f(wind, 3)), _dp(_f(lower, 3)), _dp(_f(upper, 3)),
+                         _dp(jac), _dp(res))
+    return jac, res
+
+
+def batch_cold_solve(horizon, wq, wr, wt, lower, upper, refs, meas, wind, threads=1):
+    """refs [B][N+1][16], meas [B][13], wind [B][3] -> (u, status, iters, seconds)"""
+    refs, meas, wind = _f(refs), _f(meas), _f(wind)
+    B = meas.shape[0]
+    assert refs.shape == (B, horizon + 1, 16) and wind.shape == (B, 3)
+    u = np.zeros((B, 3))
+    status = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    secs = lib().port_batch_cold_solve(
+        horizon, B, threads, _dp(_f(wq, 12)), _dp(_f(wr, 3)), _dp(_f(wt, 12)),
+        _dp(_f(lower, 3)), _dp(_f(upper, 3)), _dp(refs), _dp(meas), _dp(wind),
+        _dp(u), _ip(status), _ip(iters))
+    return u, status, iters, secs
