@@ -1,0 +1,203 @@
+"""Python wrapper of the nmpc_batch_* interface: many independent NMPC
+controllers in lockstep on one MI355X.  Method names follow the reference's
+Python module (python/nmpc/__init__.py:51-92): setup, initialise_horizon,
+set_reference, prepare, solve, get_controls, set_wind_velocity, update_horizon.
+
+Inputs may be numpy arrays (host) or torch CUDA tensors (device, float64,
+contiguous); device inputs are used in place without a copy.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class _Arg:
+    """Pointer + keep-alive for a [..] float64 input."""
+
+    def __init__(self, x, shape):
+        if _is_torch(x):
+            import torch
+            if x.dtype != torch.float64 or not x.is_contiguous():
+                raise TypeError("device inputs must be contiguous float64 tensors")
+            if tuple(x.shape) != tuple(shape):
+                raise ValueError("expected shape %s, got %s" % (shape, tuple(x.shape)))
+            self.keep = x
+            self.ptr = C.c_void_p(x.data_ptr())
+        else:
+            a = np.ascontiguousarray(x, dtype=np.float64)
+            if a.shape != tuple(shape):
+                raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+            self.keep = a
+            self.ptr = C.c_void_p(a.ctypes.data)
+
+
+def _vec(v, n):
+    a = np.ascontiguousarray(v, dtype=np.float64)
+    if a.shape != (n,):
+        raise ValueError("expected %d values" % n)
+    return a
+
+
+class Batch:
+    def __init__(self, instances, horizon=100, device=0, stream=None):
+        self.lib = _lib.load()
+        self.B, self.N = int(instances), int(horizon)
+        h = C.c_void_p()
+        _lib.check(self.lib, self.lib.nmpc_batch_create(
+            C.byref(h), self.B, self.N, int(device),
+            C.c_void_p(stream) if stream else None))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nmpc_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(self.lib, rc)
+
+    # -- configuration -------------------------------------------------
+    def setup(self, state_weights, control_weights, terminal_weights,
+              upper_control_bound, lower_control_bound):
+        dp = lambda a: a.ctypes.data_as(_lib.PREAL)
+        self._ck(self.lib.nmpc_batch_set_state_weights(self.h, dp(_vec(state_weights, 12))))
+        self._ck(self.lib.nmpc_batch_set_control_weights(self.h, dp(_vec(control_weights, 3))))
+        self._ck(self.lib.nmpc_batch_set_terminal_weights(self.h, dp(_vec(terminal_weights, 12))))
+        self._ck(self.lib.nmpc_batch_set_lower_control_bound(self.h, dp(_vec(lower_control_bound, 3))))
+        self._ck(self.lib.nmpc_batch_set_upper_control_bound(self.h, dp(_vec(upper_control_bound, 3))))
+
+    def initialise_horizon(self):
+        self._ck(self.lib.nmpc_batch_init(self.h))
+
+    def set_wind_velocity(self, wind):
+        a = _Arg(wind, (self.B, 3))
+        self._ck(self.lib.nmpc_batch_set_wind_velocity(self.h, a.ptr))
+        self._keep = [a]
+
+    def set_reference(self, points, first=0):
+        """points [B][count][16] -> horizon positions first .. first+count-1."""
+        shp = tuple(points.shape)
+        if len(shp) != 3 or shp[0] != self.B or shp[2] != 16:
+            raise ValueError("expected [B][count][16]")
+        a = _Arg(points, shp)
+        self._ck(self.lib.nmpc_batch_set_reference_points(self.h, a.ptr, int(first), shp[1]))
+        self._keep.append(a)
+
+    # -- control loop --------------------------------------------------
+    def prepare(self):
+        self._ck(self.lib.nmpc_batch_preparation_step(self.h))
+
+    def solve(self, measurement):
+        a = _Arg(measurement, (self.B, 13))
+        self._ck(self.lib.nmpc_batch_feedback_step(self.h, a.ptr))
+        self._keep.append(a)
+
+    def get_controls(self):
+        """-> (controls [B][3], status [B] (0 ok / 1 infeasible), iterations [B])"""
+        u = np.zeros((self.B, 3))
+        st = np.zeros(self.B, dtype=np.int32)
+        it = np.zeros(self.B, dtype=np.int32)
+        self._ck(self.lib.nmpc_batch_get_controls(
+            self.h, C.c_void_p(u.ctypes.data), C.c_void_p(st.ctypes.data),
+            C.c_void_p(it.ctypes.data)))
+        self._keep = []
+        return u, st, it
+
+    def get_controls_into(self, controls, status, iterations):
+        """Device-resident outputs (torch CUDA tensors: f64 [B][3], i32 [B], i32 [B])."""
+        self._ck(self.lib.nmpc_batch_get_controls(
+            self.h, C.c_void_p(controls.data_ptr()), C.c_void_p(status.data_ptr()),
+            C.c_void_p(iterations.data_ptr())))
+        self._keep = []
+
+    def update_horizon(self, new_reference):
+        a = _Arg(new_reference, (self.B, 16))
+        self._ck(self.lib.nmpc_batch_update_horizon(self.h, a.ptr))
+        self._keep.append(a)
+
+    def synchronize(self):
+        self._ck(self.lib.nmpc_batch_synchronize(self.h))
+        self._keep = []
+
+    # -- introspection ---------------------------------------------------
+    def stages(self, instance):
+        out = np.zeros((self.N + 1, 332))
+        for k in range(self.N + 1):
+            self._ck(self.lib.nmpc_batch_get_stage(
+                self.h, instance, k, out[k].ctypes.data_as(_lib.PREAL)))
+        return out
+
+    def globals_(self, instance):
+        out = np.zeros(self.lib.nmpc_batch_global_size(self.h))
+        self._ck(self.lib.nmpc_batch_get_global(self.h, instance, out.ctypes.data_as(_lib.PREAL)))
+        return out
+
+    def solver_info(self, instance):
+        info = (C.c_int32 * 6)()
+        alpha = C.c_double()
+        self._ck(self.lib.nmpc_batch_get_solver_info(self.h, instance, info, C.byref(alpha)))
+        keys = ("status", "num_iter", "last_change", "regularized", "ls_iter", "last_result")
+        d = dict(zip(keys, list(info)))
+        d["alpha"] = alpha.value
+        return d
+
+    # -- profiling -------------------------------------------------------
+    def set_profiling(self, enabled=True):
+        self._ck(self.lib.nmpc_batch_set_profiling(self.h, 1 if enabled else 0))
+
+    def kernel_times(self):
+        """{kernel name: (total ms, launches)} since profiling was enabled."""
+        out = {}
+        for i, name in enumerate(_lib.KERNEL_NAMES):
+            ms, n = C.c_double(), C.c_uint64()
+            self._ck(self.lib.nmpc_batch_get_kernel_time(self.h, i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+
+def _ptr(x):
+    if _is_torch(x):
+        return C.c_void_p(x.data_ptr()), x
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    return C.c_void_p(a.ctypes.data), a
+
+
+def linearise_samples(x, u, x_next, wind, lower, upper, device=0, out=None):
+    """Stage linearisation of n independent samples -> (jac [n][180], res [n][12])."""
+    lib = _lib.load()
+    n = int(x.shape[0])
+    px, kx = _ptr(x); pu, ku = _ptr(u); pn, kn = _ptr(x_next); pw, kw = _ptr(wind)
+    if out is None:
+        jac, res = np.zeros((n, 180)), np.zeros((n, 12))
+    else:
+        jac, res = out
+    pj, _ = (_ptr(jac) if _is_torch(jac) else (C.c_void_p(jac.ctypes.data), jac))
+    pr, _ = (_ptr(res) if _is_torch(res) else (C.c_void_p(res.ctypes.data), res))
+    lo, up = _vec(lower, 3), _vec(upper, 3)
+    _lib.check(lib, lib.nmpc_linearise_samples(
+        int(device), None, n, px, pu, pn, pw, lo.ctypes.data_as(_lib.PREAL),
+        up.ctypes.data_as(_lib.PREAL), pj, pr))
+    return jac, res
+
+
+def rk4_samples(x, u, wind, delta=1.0 / 50.0, device=0, out=None):
+    lib = _lib.load()
+    n = int(x.shape[0])
+    px, kx = _ptr(x); pu, ku = _ptr(u); pw, kw = _ptr(wind)
+    o = np.zeros((n, 13)) if out is None else out
+    po = C.c_void_p(o.data_ptr()) if _is_torch(o) else C.c_void_p(o.ctypes.data)
+    _lib.check(lib, lib.nmpc_rk4_samples(int(device), None, n, px, pu, pw, float(delta), po))
+    return o

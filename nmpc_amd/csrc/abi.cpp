@@ -1,0 +1,702 @@
+// Host side of libcnmpc.so: batch objects, the hidden single-instance
+// controller behind the reference's symbols, and the extern "C" boundary
+// declared in include/cnmpc.h.  All arithmetic is in kernels.hip; this file
+// only owns device memory, ring offsets, staging copies and launch order.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cnmpc.h"
+#include "kernels.hpp"
+
+using namespace nmpc;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess)                                                      \
+            return fail(NMPC_E_HIP, "%s failed: %s (%s:%d)", #expr,                \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define TRY(expr)                 \
+    do {                          \
+        int r_ = (expr);          \
+        if (r_ != 0) return r_;   \
+    } while (0)
+
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// A diagonal weight block within 1e-15 of the identity carries no data in the
+// reference's QP solver and behaves as exact ones
+// (ccs-c66x/qpDUNES/utils.c:106-117, setup_qp.c:229-258).
+bool is_identity(const double* w, int n) {
+    for (int i = 0; i < n; i++)
+        if (std::fabs(w[i] - 1.0) > 1e-15) return false;
+    return true;
+}
+
+struct Staging {        // grow-only device scratch for host-side inputs/outputs
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (ptr) HIP_TRY(hipFree(ptr));
+        ptr = nullptr; cap = 0;
+        HIP_TRY(hipMalloc(&ptr, bytes));
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+struct TimedLaunch { int kind; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct nmpc_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    BatchView v{};
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    double wq[12], wr[3], wt[12], lb[3], ub[3];
+    bool initialised = false;
+    Staging in_refs, in_meas, in_wind, out_u, out_status, out_iters, scratch;
+    bool profiling = false;
+    std::vector<TimedLaunch> pending;
+    std::vector<hipEvent_t> free_events;
+    double k_ms[NMPC_K_COUNT] = {0};
+    uint64_t k_count[NMPC_K_COUNT] = {0};
+};
+
+namespace {
+
+int use_device(const nmpc_batch* b) {
+    HIP_TRY(hipSetDevice(b->device));
+    return 0;
+}
+
+int get_event(nmpc_batch* b, hipEvent_t* e) {
+    if (!b->free_events.empty()) {
+        *e = b->free_events.back();
+        b->free_events.pop_back();
+        return 0;
+    }
+    HIP_TRY(hipEventCreate(e));
+    return 0;
+}
+
+// Runs `launch` on the batch's stream; with profiling on, brackets it with
+// HIP events whose elapsed time is charged to `kind`.
+template <class F>
+int timed(nmpc_batch* b, int kind, F launch) {
+    if (!b->profiling) {
+        launch();
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    TimedLaunch t{kind, nullptr, nullptr};
+    TRY(get_event(b, &t.start));
+    TRY(get_event(b, &t.stop));
+    HIP_TRY(hipEventRecord(t.start, b->stream));
+    launch();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.stop, b->stream));
+    b->pending.push_back(t);
+    return 0;
+}
+
+int drain_timings(nmpc_batch* b) {
+    for (auto& t : b->pending) {
+        HIP_TRY(hipEventSynchronize(t.stop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+        b->k_ms[t.kind] += ms;
+        b->k_count[t.kind] += 1;
+        b->free_events.push_back(t.start);
+        b->free_events.push_back(t.stop);
+    }
+    b->pending.clear();
+    return 0;
+}
+
+// Device address of `bytes` of input: the caller's pointer when it already is
+// device memory, otherwise a staged copy.
+int stage_in(nmpc_batch* b, Staging& st, const void* src, size_t bytes, const void** dev) {
+    if (is_device_pointer(src)) { *dev = src; return 0; }
+    TRY(st.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(st.ptr, src, bytes, hipMemcpyHostToDevice, b->stream));
+    *dev = st.ptr;
+    return 0;
+}
+
+void sync_config(nmpc_batch* b) {
+    memcpy(b->v.lb, b->lb, sizeof b->lb);
+    memcpy(b->v.ub, b->ub, sizeof b->ub);
+}
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+const char* nmpc_last_error(void) { return g_error.c_str(); }
+
+int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, int device,
+                      void* stream) {
+    if (!out || instances == 0 || horizon < 2)
+        return fail(NMPC_E_ARG, "nmpc_batch_create: need out != NULL, instances >= 1, horizon >= 2");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(NMPC_E_ARG, "nmpc_batch_create: device %d not present (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    nmpc_batch* b = new nmpc_batch();
+    b->device = device;
+    if (stream) {
+        b->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete b; return fail(NMPC_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        b->own_stream = true;
+    }
+    const size_t B = instances, N = horizon, N1 = N + 1;
+    BatchView& v = b->v;
+    v.B = (int)instances; v.N = (int)horizon;
+    v.head = v.xhead = v.lhead = 0;
+
+    struct Field { void** p; size_t bytes; };
+    const size_t d = sizeof(double);
+    Field fields[] = {
+        {(void**)&v.xref, B * N1 * 13 * d}, {(void**)&v.uref, B * N * 3 * d},
+        {(void**)&v.wind, B * 3 * d},
+        {(void**)&v.C, B * N * 180 * d},    {(void**)&v.c, B * N * 12 * d},
+        {(void**)&v.zLow, B * N1 * 15 * d}, {(void**)&v.zUpp, B * N1 * 15 * d},
+        {(void**)&v.q, B * N1 * 15 * d},    {(void**)&v.z, B * N1 * 15 * d},
+        {(void**)&v.qStep, B * N1 * 15 * d},{(void**)&v.zUnc, B * N1 * 15 * d},
+        {(void**)&v.dz, B * N1 * 15 * d},   {(void**)&v.tmp, B * N1 * 15 * d},
+        {(void**)&v.y, B * N1 * 30 * d},    {(void**)&v.p, B * N1 * d},
+        {(void**)&v.pStep, B * N1 * d},     {(void**)&v.lam, B * N * 12 * d},
+        {(void**)&v.dl, B * N * 12 * d},    {(void**)&v.grad, B * N * 12 * d},
+        {(void**)&v.hess, B * N * 288 * d}, {(void**)&v.chol, B * N * 288 * d},
+        {(void**)&v.ieq, B * N1 * 15},      {(void**)&v.prev, B * N1 * 15},
+        {(void**)&v.chg, B * N1},           {(void**)&v.sc, B * sizeof(Scalars)},
+    };
+    size_t total = 0;
+    for (auto& f : fields) total += align_up(f.bytes);
+    hipError_t e = hipMalloc(&b->arena, total);
+    if (e != hipSuccess) {
+        if (b->own_stream) (void)hipStreamDestroy(b->stream);
+        delete b;
+        return fail(NMPC_E_HIP, "hipMalloc(%zu bytes) failed: %s", total, hipGetErrorString(e));
+    }
+    b->arena_bytes = total;
+    e = hipMemsetAsync(b->arena, 0, total, b->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(b->arena);
+        if (b->own_stream) (void)hipStreamDestroy(b->stream);
+        delete b;
+        return fail(NMPC_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    size_t off = 0;
+    for (auto& f : fields) {
+        *f.p = (char*)b->arena + off;
+        off += align_up(f.bytes);
+    }
+    memset(b->wq, 0, sizeof b->wq); memset(b->wr, 0, sizeof b->wr);
+    memset(b->wt, 0, sizeof b->wt); memset(b->lb, 0, sizeof b->lb);
+    memset(b->ub, 0, sizeof b->ub);
+    *out = b;
+    return 0;
+}
+
+int nmpc_batch_destroy(nmpc_batch_t* b) {
+    if (!b) return 0;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    for (auto& t : b->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto ev : b->free_events) (void)hipEventDestroy(ev);
+    b->in_refs.release(); b->in_meas.release(); b->in_wind.release();
+    b->out_u.release(); b->out_status.release(); b->out_iters.release(); b->scratch.release();
+    if (b->arena) (void)hipFree(b->arena);
+    if (b->own_stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return 0;
+}
+
+int nmpc_batch_synchronize(nmpc_batch_t* b) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    TRY(use_device(b));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+#define SETTER(name, field, n)                                          \
+    int name(nmpc_batch_t* b, const real_t* coeffs) {                   \
+        if (!b || !coeffs) return fail(NMPC_E_ARG, #name ": null argument"); \
+        memcpy(b->field, coeffs, (n) * sizeof(double));                 \
+        return 0;                                                       \
+    }
+SETTER(nmpc_batch_set_state_weights, wq, 12)
+SETTER(nmpc_batch_set_control_weights, wr, 3)
+SETTER(nmpc_batch_set_terminal_weights, wt, 12)
+SETTER(nmpc_batch_set_lower_control_bound, lb, 3)
+SETTER(nmpc_batch_set_upper_control_bound, ub, 3)
+#undef SETTER
+
+int nmpc_batch_init(nmpc_batch_t* b) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    TRY(use_device(b));
+    BatchView& v = b->v;
+    const bool idq = is_identity(b->wq, 12), idr = is_identity(b->wr, 3);
+    for (int i = 0; i < 12; i++) v.H[i] = idq ? 1. : b->wq[i];
+    for (int i = 0; i < 3; i++) v.H[12 + i] = idr ? 1. : b->wr[i];
+    const bool idt = is_identity(b->wt, 12);
+    for (int i = 0; i < 12; i++) v.Ht[i] = idt ? 1. : b->wt[i];
+    sync_config(b);
+    v.head = 0;   // the interval order is rebuilt (ccs-c66x/cnmpc.c:817-828)
+    TRY(timed(b, NMPC_K_OTHER, [&] { launch_init_stages(v, b->stream); }));
+    b->initialised = true;
+    return 0;
+}
+
+int nmpc_batch_set_wind_velocity(nmpc_batch_t* b, const real_t* wind) {
+    if (!b || !wind) return fail(NMPC_E_ARG, "nmpc_batch_set_wind_velocity: null argument");
+    TRY(use_device(b));
+    HIP_TRY(hipMemcpyAsync(b->v.wind, wind, (size_t)b->v.B * 3 * sizeof(double),
+                           hipMemcpyDefault, b->stream));
+    if (!is_device_pointer(wind)) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_t first,
+                                    uint32_t count) {
+    if (!b || !refs) return fail(NMPC_E_ARG, "nmpc_batch_set_reference_points: null argument");
+    if (count == 0) return 0;
+    if ((uint64_t)first + count > (uint64_t)b->v.N + 1)
+        return fail(NMPC_E_ARG, "reference index %u beyond horizon %d", first + count - 1, b->v.N);
+    TRY(use_device(b));
+    sync_config(b);
+    const void* dev = nullptr;
+    const bool host = !is_device_pointer(refs);
+    TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(double), &dev));
+    TRY(timed(b, NMPC_K_OTHER, [&] {
+        launch_store_refs(b->v, (const double*)dev, (int)first, (int)count, b->stream);
+    }));
+    // point i linearises stage i-1
+    const int lin_first = first == 0 ? 0 : (int)first - 1;
+    const int lin_count = first == 0 ? (int)count - 1 : (int)count;
+    if (lin_count > 0)
+        TRY(timed(b, NMPC_K_LINEARISE, [&] {
+            launch_linearise(b->v, lin_first, lin_count, b->stream);
+        }));
+    if (host) HIP_TRY(hipStreamSynchronize(b->stream));   // caller may reuse its buffer
+    return 0;
+}
+
+int nmpc_batch_preparation_step(nmpc_batch_t* b) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    return 0;
+}
+
+int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
+    if (!b || !measurement) return fail(NMPC_E_ARG, "nmpc_batch_feedback_step: null argument");
+    if (!b->initialised) return fail(NMPC_E_STATE, "nmpc_batch_feedback_step before nmpc_batch_init");
+    TRY(use_device(b));
+    sync_config(b);
+    const void* dev = nullptr;
+    const bool host = !is_device_pointer(measurement);
+    TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(double), &dev));
+    BatchView& v = b->v;
+    TRY(timed(b, NMPC_K_QP_BEGIN, [&] { launch_qp_begin(v, (const double*)dev, b->stream); }));
+    for (int it = 1; it <= max_newton_iterations(); ++it) {
+        TRY(timed(b, NMPC_K_NEWTON_SETUP, [&] { launch_newton_setup(v, it, b->stream); }));
+        TRY(timed(b, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, b->stream); }));
+        TRY(timed(b, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, b->stream); }));
+    }
+    TRY(timed(b, NMPC_K_OTHER, [&] { launch_qp_finish(v, b->stream); }));
+    if (host) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int nmpc_batch_get_controls(nmpc_batch_t* b, real_t* controls, int32_t* status,
+                            int32_t* iterations) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    TRY(use_device(b));
+    const size_t B = (size_t)b->v.B;
+    const bool du = controls && is_device_pointer(controls);
+    const bool ds = status && is_device_pointer(status);
+    const bool di = iterations && is_device_pointer(iterations);
+    TRY(b->out_u.reserve(B * 3 * sizeof(double)));
+    TRY(b->out_status.reserve(B * sizeof(int)));
+    TRY(b->out_iters.reserve(B * sizeof(int)));
+    double* pu = du ? controls : (double*)b->out_u.ptr;
+    int* ps = ds ? status : (int*)b->out_status.ptr;
+    int* pi = di ? iterations : (int*)b->out_iters.ptr;
+    TRY(timed(b, NMPC_K_OTHER, [&] { launch_gather_results(b->v, pu, ps, pi, b->stream); }));
+    if (controls && !du)
+        HIP_TRY(hipMemcpyAsync(controls, pu, B * 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    if (status && !ds)
+        HIP_TRY(hipMemcpyAsync(status, ps, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    if (iterations && !di)
+        HIP_TRY(hipMemcpyAsync(iterations, pi, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
+    if (!b || !new_reference) return fail(NMPC_E_ARG, "nmpc_batch_update_horizon: null argument");
+    TRY(use_device(b));
+    sync_config(b);
+    BatchView& v = b->v;
+    const void* dev = nullptr;
+    const bool host = !is_device_pointer(new_reference);
+    TRY(stage_in(b, b->in_refs, new_reference, (size_t)v.B * 16 * sizeof(double), &dev));
+    // shift references, multipliers and stage records by one position
+    v.xhead = (v.xhead + 1) % (v.N + 1);
+    v.lhead = (v.lhead + 1) % v.N;
+    v.head = (v.head + 1) % v.N;
+    TRY(timed(b, NMPC_K_OTHER, [&] { launch_shift_lambda_tail(v, b->stream); }));
+    TRY(timed(b, NMPC_K_OTHER, [&] {
+        launch_store_refs(v, (const double*)dev, v.N, 1, b->stream);
+    }));
+    TRY(timed(b, NMPC_K_LINEARISE, [&] { launch_linearise(v, v.N - 1, 1, b->stream); }));
+    if (host) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+uint32_t nmpc_batch_instances(const nmpc_batch_t* b) { return b ? (uint32_t)b->v.B : 0; }
+uint32_t nmpc_batch_horizon(const nmpc_batch_t* b) { return b ? (uint32_t)b->v.N : 0; }
+
+// ---- introspection ---------------------------------------------------------
+static int d2h(nmpc_batch* b, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->stream));
+    return 0;
+}
+
+int nmpc_batch_get_stage(nmpc_batch_t* b, uint32_t instance, uint32_t k, real_t* o) {
+    if (!b || !o) return fail(NMPC_E_ARG, "nmpc_batch_get_stage: null argument");
+    const BatchView& v = b->v;
+    if (instance >= (uint32_t)v.B || k > (uint32_t)v.N)
+        return fail(NMPC_E_ARG, "nmpc_batch_get_stage: index out of range");
+    TRY(use_device(b));
+    const size_t N = v.N, N1 = N + 1, ib = instance;
+    const size_t s = k < N ? (size_t)((v.head + k) % v.N) : N;
+    const size_t nv = k < N ? 15 : 12;
+    memset(o, 0, 332 * sizeof(double));
+    const size_t d = sizeof(double);
+    if (k < N) {
+        TRY(d2h(b, o, v.C + (ib * N + s) * 180, 180 * d));
+        TRY(d2h(b, o + 180, v.c + (ib * N + s) * 12, 12 * d));
+    }
+    const size_t so = (ib * N1 + s) * 15;
+    TRY(d2h(b, o + 192, v.zLow + so, nv * d));
+    TRY(d2h(b, o + 207, v.zUpp + so, nv * d));
+    TRY(d2h(b, o + 222, v.q + so, nv * d));
+    TRY(d2h(b, o + 237, v.p + ib * N1 + s, d));
+    TRY(d2h(b, o + 238, v.z + so, nv * d));
+    TRY(d2h(b, o + 253, v.y + 2 * so, 2 * nv * d));
+    TRY(d2h(b, o + 283, v.qStep + so, nv * d));
+    TRY(d2h(b, o + 298, v.pStep + ib * N1 + s, d));
+    TRY(d2h(b, o + 299, v.zUnc + so, nv * d));
+    TRY(d2h(b, o + 314, v.dz + so, nv * d));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+uint32_t nmpc_batch_global_size(const nmpc_batch_t* b) {
+    if (!b) return 0;
+    const uint32_t N = (uint32_t)b->v.N;
+    return 3 * 12 * N + 2 * 288 * N + 2 * 15 * (N + 1) + 13 * (N + 1) + 3 * N + 3;
+}
+
+int nmpc_batch_get_global(nmpc_batch_t* b, uint32_t instance, real_t* o) {
+    if (!b || !o) return fail(NMPC_E_ARG, "nmpc_batch_get_global: null argument");
+    const BatchView& v = b->v;
+    if (instance >= (uint32_t)v.B) return fail(NMPC_E_ARG, "instance out of range");
+    TRY(use_device(b));
+    const size_t N = v.N, N1 = N + 1, ib = instance, d = sizeof(double);
+    // lambda, position order
+    for (size_t k = 0; k < N; k++) {
+        const size_t ls = (size_t)((v.lhead + (int)k) % v.N);
+        TRY(d2h(b, o + 12 * k, v.lam + (ib * N + ls) * 12, 12 * d));
+    }
+    o += 12 * N;
+    TRY(d2h(b, o, v.dl + ib * N * 12, 12 * N * d)); o += 12 * N;
+    TRY(d2h(b, o, v.grad + ib * N * 12, 12 * N * d)); o += 12 * N;
+    TRY(d2h(b, o, v.hess + ib * N * 288, 288 * N * d)); o += 288 * N;
+    TRY(d2h(b, o, v.chol + ib * N * 288, 288 * N * d)); o += 288 * N;
+    std::vector<int8_t> ie(N1 * 15), pr(N1 * 15);
+    TRY(d2h(b, ie.data(), v.ieq + ib * N1 * 15, N1 * 15));
+    TRY(d2h(b, pr.data(), v.prev + ib * N1 * 15, N1 * 15));
+    double* oi = o; o += 15 * N1;
+    double* op = o; o += 15 * N1;
+    for (size_t k = 0; k < N1; k++) {
+        const size_t xs = (size_t)((v.xhead + (int)k) % (v.N + 1));
+        TRY(d2h(b, o + 13 * k, v.xref + (ib * N1 + xs) * 13, 13 * d));
+    }
+    o += 13 * N1;
+    for (size_t k = 0; k < N; k++) {
+        const size_t s = (size_t)((v.head + (int)k) % v.N);
+        TRY(d2h(b, o + 3 * k, v.uref + (ib * N + s) * 3, 3 * d));
+    }
+    o += 3 * N;
+    Scalars sc;
+    TRY(d2h(b, &sc, v.sc + ib, sizeof sc));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (size_t k = 0; k < N1; k++)
+        for (size_t i = 0; i < 15; i++) {
+            const bool valid = i < (k < N ? 15u : 12u);
+            oi[k * 15 + i] = valid ? (double)ie[k * 15 + i] : 0.0;
+            op[k * 15 + i] = valid ? (double)pr[k * 15 + i] : 0.0;
+        }
+    o[0] = sc.u[0]; o[1] = sc.u[1]; o[2] = sc.u[2];
+    return 0;
+}
+
+int nmpc_batch_get_solver_info(nmpc_batch_t* b, uint32_t instance, int32_t info[6],
+                               real_t* alpha) {
+    if (!b || !info) return fail(NMPC_E_ARG, "nmpc_batch_get_solver_info: null argument");
+    if (instance >= (uint32_t)b->v.B) return fail(NMPC_E_ARG, "instance out of range");
+    TRY(use_device(b));
+    Scalars sc;
+    TRY(d2h(b, &sc, b->v.sc + instance, sizeof sc));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    info[0] = sc.status; info[1] = sc.numIter; info[2] = sc.last;
+    info[3] = sc.regularized; info[4] = sc.lsIter; info[5] = sc.lastResult;
+    if (alpha) *alpha = sc.alpha;
+    return 0;
+}
+
+int nmpc_batch_set_profiling(nmpc_batch_t* b, int enabled) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    TRY(use_device(b));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    TRY(drain_timings(b));
+    b->profiling = enabled != 0;
+    if (enabled)
+        for (int i = 0; i < NMPC_K_COUNT; i++) { b->k_ms[i] = 0; b->k_count[i] = 0; }
+    return 0;
+}
+
+int nmpc_batch_get_kernel_time(nmpc_batch_t* b, int kernel, double* total_ms, uint64_t* launches) {
+    if (!b || kernel < 0 || kernel >= NMPC_K_COUNT)
+        return fail(NMPC_E_ARG, "nmpc_batch_get_kernel_time: bad argument");
+    TRY(use_device(b));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    TRY(drain_timings(b));
+    if (total_ms) *total_ms = b->k_ms[kernel];
+    if (launches) *launches = b->k_count[kernel];
+    return 0;
+}
+
+// ---- stateless sample kernels --------------------------------------------------
+namespace {
+struct TempCopy {       // device copy of a host input / device home of a host output
+    void* dev = nullptr;
+    bool owned = false;
+    ~TempCopy() { if (owned && dev) (void)hipFree(dev); }
+};
+int temp_in(TempCopy& t, const void* src, size_t bytes, hipStream_t s) {
+    if (is_device_pointer(src)) { t.dev = (void*)src; return 0; }
+    HIP_TRY(hipMalloc(&t.dev, bytes));
+    t.owned = true;
+    HIP_TRY(hipMemcpyAsync(t.dev, src, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+int temp_out(TempCopy& t, void* dst, size_t bytes) {
+    if (is_device_pointer(dst)) { t.dev = dst; return 0; }
+    HIP_TRY(hipMalloc(&t.dev, bytes));
+    t.owned = true;
+    return 0;
+}
+int finish_out(TempCopy& t, void* dst, size_t bytes, hipStream_t s) {
+    if (t.owned) HIP_TRY(hipMemcpyAsync(dst, t.dev, bytes, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+}  // namespace
+
+int nmpc_linearise_samples(int device, void* stream, uint64_t n, const real_t* x, const real_t* u,
+                           const real_t* x_next, const real_t* wind, const real_t lower[3],
+                           const real_t upper[3], real_t* jacobian, real_t* residual) {
+    if (!x || !u || !x_next || !wind || !lower || !upper || !jacobian || !residual)
+        return fail(NMPC_E_ARG, "nmpc_linearise_samples: null argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t d = sizeof(double);
+    TempCopy tx, tu, tn, tw, tj, tr;
+    TRY(temp_in(tx, x, n * 13 * d, s)); TRY(temp_in(tu, u, n * 3 * d, s));
+    TRY(temp_in(tn, x_next, n * 13 * d, s)); TRY(temp_in(tw, wind, n * 3 * d, s));
+    TRY(temp_out(tj, jacobian, n * 180 * d)); TRY(temp_out(tr, residual, n * 12 * d));
+    Bounds bnd;
+    memcpy(bnd.lb, lower, sizeof bnd.lb); memcpy(bnd.ub, upper, sizeof bnd.ub);
+    launch_linearise_free((long)n, (const double*)tx.dev, (const double*)tu.dev,
+                          (const double*)tn.dev, (const double*)tw.dev, bnd, (double*)tj.dev,
+                          (double*)tr.dev, s);
+    HIP_TRY(hipGetLastError());
+    TRY(finish_out(tj, jacobian, n * 180 * d, s));
+    TRY(finish_out(tr, residual, n * 12 * d, s));
+    const bool any_host = tx.owned || tu.owned || tn.owned || tw.owned || tj.owned || tr.owned;
+    if (any_host) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int nmpc_rk4_samples(int device, void* stream, uint64_t n, const real_t* x, const real_t* u,
+                     const real_t* wind, real_t delta, real_t* out) {
+    if (!x || !u || !wind || !out) return fail(NMPC_E_ARG, "nmpc_rk4_samples: null argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t d = sizeof(double);
+    TempCopy tx, tu, tw, to;
+    TRY(temp_in(tx, x, n * 13 * d, s)); TRY(temp_in(tu, u, n * 3 * d, s));
+    TRY(temp_in(tw, wind, n * 3 * d, s)); TRY(temp_out(to, out, n * 13 * d));
+    launch_rk4_free((long)n, (const double*)tx.dev, (const double*)tu.dev, (const double*)tw.dev,
+                    delta, (double*)to.dev, s);
+    HIP_TRY(hipGetLastError());
+    TRY(finish_out(to, out, n * 13 * d, s));
+    if (tx.owned || tu.owned || tw.owned || to.owned) HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ============================================================================
+// Reference controller interface: one hidden instance.
+// ============================================================================
+namespace {
+
+struct Single {
+    nmpc_batch* batch = nullptr;
+    double wq[12] = {0}, wr[3] = {0}, wt[12] = {0}, lb[3] = {0}, ub[3] = {0};
+    double wind[3] = {0};
+    double plant[13] = {0};     // c/cnmpc.cpp:33 `current`
+};
+Single g_single;
+
+[[noreturn]] void die(const char* what) {
+    fprintf(stderr, "libcnmpc: %s: %s\n", what, g_error.c_str());
+    abort();
+}
+#define MUST(expr) do { if ((expr) != 0) die(#expr); } while (0)
+
+nmpc_batch* single() {
+    if (!g_single.batch) {
+        int dev = 0;
+        if (const char* e = getenv("NMPC_DEVICE")) dev = atoi(e);
+        MUST(nmpc_batch_create(&g_single.batch, 1, OCP_HORIZON_LENGTH, dev, nullptr));
+    }
+    return g_single.batch;
+}
+
+void push_config(nmpc_batch* b) {
+    memcpy(b->wq, g_single.wq, sizeof b->wq); memcpy(b->wr, g_single.wr, sizeof b->wr);
+    memcpy(b->wt, g_single.wt, sizeof b->wt); memcpy(b->lb, g_single.lb, sizeof b->lb);
+    memcpy(b->ub, g_single.ub, sizeof b->ub);
+}
+
+}  // namespace
+
+void nmpc_init(void) {
+    nmpc_batch* b = single();
+    push_config(b);
+    MUST(nmpc_batch_init(b));
+    MUST(nmpc_batch_set_wind_velocity(b, g_single.wind));
+}
+
+void nmpc_preparation_step(void) {}
+
+void nmpc_feedback_step(real_t measurement[NMPC_STATE_DIM]) {
+    nmpc_batch* b = single();
+    push_config(b);
+    MUST(nmpc_batch_feedback_step(b, measurement));
+}
+
+enum nmpc_result_t nmpc_get_controls(real_t controls[NMPC_CONTROL_DIM]) {
+    int32_t status = 0;
+    MUST(nmpc_batch_get_controls(single(), controls, &status, nullptr));
+    return status == 0 ? NMPC_OK : NMPC_INFEASIBLE;
+}
+
+void nmpc_update_horizon(real_t new_reference[NMPC_REFERENCE_DIM]) {
+    nmpc_batch* b = single();
+    push_config(b);
+    MUST(nmpc_batch_update_horizon(b, new_reference));
+}
+
+void nmpc_set_state_weights(real_t coeffs[NMPC_DELTA_DIM]) { memcpy(g_single.wq, coeffs, sizeof g_single.wq); }
+void nmpc_set_control_weights(real_t coeffs[NMPC_CONTROL_DIM]) { memcpy(g_single.wr, coeffs, sizeof g_single.wr); }
+void nmpc_set_terminal_weights(real_t coeffs[NMPC_DELTA_DIM]) { memcpy(g_single.wt, coeffs, sizeof g_single.wt); }
+void nmpc_set_lower_control_bound(real_t coeffs[NMPC_CONTROL_DIM]) { memcpy(g_single.lb, coeffs, sizeof g_single.lb); }
+void nmpc_set_upper_control_bound(real_t coeffs[NMPC_CONTROL_DIM]) { memcpy(g_single.ub, coeffs, sizeof g_single.ub); }
+
+void nmpc_set_reference_point(real_t coeffs[NMPC_REFERENCE_DIM], uint32_t i) {
+    nmpc_batch* b = single();
+    push_config(b);
+    MUST(nmpc_batch_set_reference_points(b, coeffs, i, 1));
+}
+
+void nmpc_set_wind_velocity(real_t x, real_t y, real_t z) {
+    g_single.wind[0] = x; g_single.wind[1] = y; g_single.wind[2] = z;
+    if (g_single.batch) MUST(nmpc_batch_set_wind_velocity(g_single.batch, g_single.wind));
+}
+
+void nmpc_fixedwingdynamics_set_position(real_t lat, real_t lon, real_t alt) {
+    g_single.plant[0] = lat; g_single.plant[1] = lon; g_single.plant[2] = alt;
+}
+void nmpc_fixedwingdynamics_set_velocity(real_t x, real_t y, real_t z) {
+    g_single.plant[3] = x; g_single.plant[4] = y; g_single.plant[5] = z;
+}
+void nmpc_fixedwingdynamics_set_attitude(real_t w, real_t x, real_t y, real_t z) {
+    g_single.plant[6] = x; g_single.plant[7] = y; g_single.plant[8] = z; g_single.plant[9] = w;
+}
+void nmpc_fixedwingdynamics_set_angular_velocity(real_t x, real_t y, real_t z) {
+    g_single.plant[10] = x; g_single.plant[11] = y; g_single.plant[12] = z;
+}
+void nmpc_fixedwingdynamics_set_state(struct nmpc_state_t* in) { memcpy(g_single.plant, in, sizeof g_single.plant); }
+void nmpc_fixedwingdynamics_get_state(struct nmpc_state_t* in) { memcpy(in, g_single.plant, sizeof g_single.plant); }
+
+void nmpc_fixedwingdynamics_integrate(float dt, real_t control_vector[NMPC_CONTROL_DIM]) {
+    nmpc_batch* b = single();
+    double next[13];
+    MUST(nmpc_rk4_samples(b->device, nullptr, 1, g_single.plant, control_vector, g_single.wind,
+                          (double)dt, next));
+    memcpy(g_single.plant, next, sizeof next);
+}
+
+uint32_t nmpc_config_get_state_dim(void) { return NMPC_STATE_DIM; }
+uint32_t nmpc_config_get_control_dim(void) { return NMPC_CONTROL_DIM; }
+uint32_t nmpc_config_get_horizon_length(void) { return OCP_HORIZON_LENGTH; }
+real_t nmpc_config_get_step_length(void) { return OCP_STEP_LENGTH; }
+enum nmpc_precision_t nmpc_config_get_precision(void) { return NMPC_PRECISION_DOUBLE; }
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// Device-memory plan of one batch of NMPC instances (replaces the reference's
+// per-process static_qpdata_t / static_interval_t, ccs-c66x/cnmpc.c:52-117, and
+// qpDUNES' interval_t / qpData_t, ccs-c66x/qpDUNES/types.h:411-693).
+//
+// Field-major arrays, instance index slowest: X[b][stage][...].  The Hessians
+// of the stage QPs are diagonal and identical for every regular stage, so they
+// are two small vectors, not 15x15 matrices per stage.
+//
+// Horizon shifting moves no data.  Three ring offsets map a horizon position
+// to a physical slot:
+//   stage ring  (C, c, bounds, z, y, q, p, step data, uref): position k < N is
+//               slot (head + k) % N; the terminal stage is always slot N.
+//               This is the reference's interval-pointer rotation
+//               (qpDUNES/setup_qp.c:619-642).
+//   xref ring   N+1 slots, position k is slot (xhead + k) % (N + 1)
+//               (the memmove at ccs-c66x/cnmpc.c:976-977).
+//   lambda ring N slots, position k is slot (lhead + k) % N
+//               (qpDUNES_shiftLambda, qpDUNES/setup_qp.c:650-662).
+// The Newton system (hess, chol, grad, dl) and the active-set records are
+// indexed by position and never shifted, exactly as in the reference.
+#pragma once
+#include <stdint.h>
+
+namespace nmpc {
+
+// Solver status codes: numeric values of qpDUNES' return_t
+// (ccs-c66x/qpDUNES/types.h:211-231) plus RUNNING for an unfinished solve.
+enum : int {
+    ST_RUNNING = -1,
+    ST_OK = 0,
+    ST_OPTIMAL = 1,
+    ST_ITER_LIMIT = 8,
+    ST_DIV_ZERO = 9,
+    ST_LS_MAXITER = 10,
+    ST_LS_MIN_STEP = 11,
+    ST_LS_MAX_STEP = 12,
+    ST_NO_ASCENT = 13
+};
+
+struct Scalars {        // one per instance
+    double objInc;      // incumbent dual objective
+    double alpha;       // last step length
+    double u[3];        // last good controls
+    int status;         // ST_*
+    int numIter;        // qpData.log.numIter
+    int last;           // lastActSetChangeIdx
+    int regularized;    // Newton Hessian regularised this iteration
+    int lsIter;         // line-search trial count of the last iteration
+    int lastResult;     // 1 = nmpc_get_controls would return NMPC_OK
+};
+
+struct BatchView {
+    int B, N;
+    int head, xhead, lhead;
+    double* xref;       // [B][N+1][13]
+    double* uref;       // [B][N][3]      stage slot
+    double* wind;       // [B][3]
+    double* C;          // [B][N][12*15]  stage slot, row-major 12x15
+    double* c;          // [B][N][12]
+    double* zLow;       // [B][N+1][15]
+    double* zUpp;
+    double* q;
+    double* z;
+    double* qStep;
+    double* zUnc;
+    double* dz;
+    double* tmp;        // trial primal vector of the line search
+    double* y;          // [B][N+1][30]   (lb - z, z - ub) pairs
+    double* p;          // [B][N+1]
+    double* pStep;      // [B][N+1]
+    double* lam;        // [B][N][12]     lambda ring
+    double* dl;         // [B][N][12]
+    double* grad;       // [B][N][12]
+    double* hess;       // [B][N][12][24] "[L D]" block rows (types.h:265-283)
+    double* chol;       // [B][N][12][24]
+    int8_t* ieq;        // [B][N+1][15]
+    int8_t* prev;       // [B][N+1][15]
+    int8_t* chg;        // [B][N+1]       actSetHasChanged
+    Scalars* sc;        // [B]
+    double H[15];       // regular-stage Hessian diagonal as the solver sees it
+    double Ht[12];      // terminal-stage Hessian diagonal
+    double lb[3], ub[3];
+};
+
+}  // namespace nmpc
