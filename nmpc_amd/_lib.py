@@ -97,6 +97,21 @@ PROTOTYPES = {
 _lib = None
 
 
+def _load_torch_first():
+    """PyTorch-ROCm wheels bundle their own HIP runtime under the same soname
+    as the system one (libamdhip64.so.7).  The copy loaded first serves every
+    later user; if libcnmpc.so pulled in the system copy first, a later
+    `import torch` would bring a second runtime into the process and fail with
+    "No HIP GPUs are available".  So torch, when installed, goes first.
+    Set NMPC_AMD_NO_TORCH=1 to skip this in torch-free deployments."""
+    if os.environ.get("NMPC_AMD_NO_TORCH") == "1":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load(path=None):
     """Load the shared library and attach prototypes.  Raises if it is absent."""
     global _lib
@@ -107,6 +122,7 @@ def load(path=None):
         raise NmpcError(
             "%s not found: build it with `make -C nmpc_amd/csrc` (hipcc, gfx950); "
             "there is no CPU fallback" % p)
+    _load_torch_first()
     lib = C.CDLL(p)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing

@@ -1,0 +1,38 @@
+"""Instance partitioning for one-process-per-GPU runs.
+
+Controller instances are independent, so rank r of `world` owns the contiguous
+instance range instance_range(total, world, r); its per-instance state never
+leaves its GPU.  The only exchange is the gather of the per-step results
+(controls 3 x f64, status i32, iterations i32 per instance)."""
+
+
+def instance_range(total, world, rank):
+    base, extra = divmod(int(total), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_results(controls, status, iterations, group=None):
+    """All-gather of per-rank results along the instance axis with
+    torch.distributed (RCCL over xGMI on GPUs, gloo on CPU).  Inputs are torch
+    tensors [b_r][3] f64, [b_r] i32, [b_r] i32 with possibly unequal b_r;
+    returns the concatenation over ranks in rank order."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n = torch.tensor([controls.shape[0]], dtype=torch.int64, device=controls.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    # one packed f64 record per instance: u0 u1 u2 status iterations
+    rec = torch.zeros((m, 5), dtype=torch.float64, device=controls.device)
+    b = controls.shape[0]
+    rec[:b, 0:3] = controls
+    rec[:b, 3] = status.to(torch.float64)
+    rec[:b, 4] = iterations.to(torch.float64)
+    parts = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(parts, rec, group=group)
+    full = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    return (full[:, 0:3].contiguous(), full[:, 3].to(torch.int32), full[:, 4].to(torch.int32))

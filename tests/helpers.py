@@ -1,0 +1,99 @@
+"""Shared test plumbing: golden fixtures and sequence drivers for the CPU
+oracle port and for the HIP library."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SEQUENCES = ["seq_straight", "seq_turn0", "seq_turn1", "seq_turn2", "seq_turn3",
+             "seq_turn4", "seq_turn5", "seq_bound", "seq_identity", "seq_regularised",
+             "seq_linesearch", "seq_exact", "seq_n500_0", "seq_n500_1"]
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def config_of(g):
+    return dict(state_weights=g["state_weights"], control_weights=g["control_weights"],
+                terminal_weights=g["terminal_weights"], upper_control_bound=g["upper"],
+                lower_control_bound=g["lower"])
+
+
+def drive_port(g, dump=False):
+    """Replay a golden sequence through the CPU oracle port."""
+    import portdriver as P
+    N = int(g["horizon"])
+    steps = len(g["u"])
+    c = config_of(g)
+    p = P.Port(N)
+    p.setup(c["state_weights"], c["control_weights"], c["terminal_weights"],
+            c["upper_control_bound"], c["lower_control_bound"])
+    p.init()
+    p.set_wind(g["winds"][0])
+    for i in range(N + 1):
+        p.set_reference(g["refs"][i], i)
+    out = dict(u=np.zeros((steps, 3)), status=np.zeros(steps, np.int32),
+               iters=np.zeros(steps, np.int32), z0=np.zeros((steps, 15)))
+    if dump:
+        out["loaded_Cc"] = p.stages()[:, :192].copy()
+    for k in range(steps):
+        p.set_wind(g["winds"][k])
+        p.feedback(g["meas"][k])
+        out["u"][k], out["status"][k] = p.controls()
+        out["iters"][k] = p.num_iter()
+        out["z0"][k] = p.stages()[0, 238:253]
+        p.update_horizon(g["refs"][N + 1 + k])
+    if dump:
+        out["final_stages"] = p.stages()
+        out["final_globals"] = p.globals_()
+    return out
+
+
+def drive_gpu_batch(gs, dump=False):
+    """Replay golden sequences of equal horizon, step count and configuration
+    as one batch through libcnmpc.so (batch interface)."""
+    from nmpc_amd.batch import Batch
+    g0 = gs[0]
+    N = int(g0["horizon"])
+    steps = len(g0["u"])
+    B = len(gs)
+    bt = Batch(B, N)
+    bt.setup(**config_of(g0))
+    bt.initialise_horizon()
+    bt.set_wind_velocity(np.stack([g["winds"][0] for g in gs]))
+    bt.set_reference(np.stack([g["refs"][:N + 1] for g in gs]))
+    out = dict(u=np.zeros((B, steps, 3)), status=np.zeros((B, steps), np.int32),
+               iters=np.zeros((B, steps), np.int32), z0=np.zeros((B, steps, 15)))
+    if dump:
+        out["loaded_Cc"] = [bt.stages(b)[:, :192].copy() for b in range(B)]
+    for k in range(steps):
+        bt.prepare()
+        bt.set_wind_velocity(np.stack([g["winds"][k] for g in gs]))
+        bt.solve(np.stack([g["meas"][k] for g in gs]))
+        u, st, it = bt.get_controls()
+        out["u"][:, k], out["status"][:, k], out["iters"][:, k] = u, st, it
+        for b in range(B):
+            rec = np.zeros(332)
+            bt._ck(bt.lib.nmpc_batch_get_stage(
+                bt.h, b, 0, rec.ctypes.data_as(__import__("ctypes").POINTER(
+                    __import__("ctypes").c_double))))
+            out["z0"][b, k] = rec[238:253]
+        bt.update_horizon(np.stack([g["refs"][N + 1 + k] for g in gs]))
+    if dump:
+        out["final_stages"] = [bt.stages(b) for b in range(B)]
+        out["final_globals"] = [bt.globals_(b) for b in range(B)]
+    bt.close()
+    return out
+
+
+def assert_same(a, b, what):
+    """Bit-for-bit equality with a readable first difference."""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    if not np.array_equal(a, b):
+        d = np.argwhere(a != b)
+        i = tuple(d[0])
+        raise AssertionError("%s: %d of %d entries differ, first at %s: %r vs %r" % (
+            what, len(d), a.size, i, a[i], b[i]))

@@ -1,0 +1,299 @@
+"""GPU parity tests (pytest -m gpu): libcnmpc.so, called through its C ABI,
+against the committed golden vectors of the compiled reference and against
+the CPU oracle port on the same seeded inputs.
+
+Bar: controls and Jacobians within 1e-9 relative of the reference fp64 CPU
+path and identical QP iteration counts.  The kernels are built without FMA
+contraction and reproduce the reference's operation order, so these tests
+assert the stronger property -- bit-for-bit equality -- for every quantity.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import SEQUENCES, assert_same, config_of, drive_gpu_batch, golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rk4_samples_golden():
+    from nmpc_amd.batch import rk4_samples
+    g = golden("model")
+    out = rk4_samples(g["x"], g["u"], g["wind"])
+    assert_same(out, g["xplus"], "x+ (RK4)")
+
+
+def test_linearise_samples_golden():
+    from nmpc_amd.batch import linearise_samples
+    g = golden("linearise")
+    jac, res = linearise_samples(g["x"], g["u"], g["xnext"], g["wind"], g["lower"], g["upper"])
+    np.testing.assert_allclose(jac, g["jac"], rtol=1e-9, atol=0)    # the stated bar
+    assert_same(jac, g["jac"], "Jacobian")
+    assert_same(res, g["res"], "residual")
+
+
+def test_linearise_ragged_and_empty():
+    """Sample counts that do not fill a 16-lane group / a workgroup, and n = 0."""
+    from nmpc_amd import _lib
+    from nmpc_amd.batch import linearise_samples
+    g = golden("linearise")
+    for n in (1, 3, 17, 255):
+        jac, res = linearise_samples(g["x"][:n], g["u"][:n], g["xnext"][:n], g["wind"][:n],
+                                     g["lower"], g["upper"])
+        assert_same(jac, g["jac"][:n], "Jacobian n=%d" % n)
+        assert_same(res, g["res"][:n], "residual n=%d" % n)
+    lib = _lib.load()
+    z = np.zeros(1)
+    p = ctypes.c_void_p(z.ctypes.data)
+    lo = g["lower"].ctypes.data_as(_lib.PREAL)
+    assert lib.nmpc_linearise_samples(0, None, 0, p, p, p, p, lo, lo, p, p) == 0
+
+
+@pytest.mark.parametrize("name", [s for s in SEQUENCES if not s.startswith("seq_turn")])
+def test_sequence_golden(name):
+    g = golden(name)
+    dump = "final_stages" in g
+    out = drive_gpu_batch([g], dump=dump)
+    assert_same(out["status"][0], g["status"], name + " status")
+    assert_same(out["iters"][0], g["iters"], name + " QP iterations")
+    np.testing.assert_allclose(out["u"][0], g["u"], rtol=1e-9, atol=0)
+    assert_same(out["u"][0], g["u"], name + " controls")
+    assert_same(out["z0"][0], g["z0"], name + " z0")
+    if dump:
+        assert_same(out["loaded_Cc"][0], g["loaded_Cc"], name + " C,c after loading")
+        assert_same(out["final_stages"][0], g["final_stages"], name + " final stage records")
+        assert_same(out["final_globals"][0], g["final_globals"], name + " final solver state")
+
+
+def test_turn_sequences_as_one_batch():
+    """Six 50-step closed-loop sequences with wind changes run in lockstep as
+    one batch: per-instance results must not depend on batch neighbours."""
+    gs = [golden("seq_turn%d" % b) for b in range(6)]
+    out = drive_gpu_batch(gs)
+    for b, g in enumerate(gs):
+        assert_same(out["status"][b], g["status"], "turn%d status" % b)
+        assert_same(out["iters"][b], g["iters"], "turn%d QP iterations" % b)
+        assert_same(out["u"][b], g["u"], "turn%d controls" % b)
+        assert_same(out["z0"][b], g["z0"], "turn%d z0" % b)
+
+
+def test_reference_interface_in_fresh_process():
+    """The 24 reference symbols through the Python module mirror, in a child
+    process so that the hidden instance starts from zeroed state."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import golden
+import nmpc_amd as nmpc
+g = golden("seq_straight")
+nmpc.init()
+assert nmpc.HORIZON_LENGTH == 100 and nmpc.STEP_LENGTH == 0.02
+nmpc.setup(state_weights=list(g["state_weights"]), control_weights=list(g["control_weights"]),
+           terminal_weights=list(g["terminal_weights"]), upper_control_bound=list(g["upper"]),
+           lower_control_bound=list(g["lower"]))
+nmpc.initialise_horizon()
+for i in range(nmpc.HORIZON_LENGTH + 1):
+    nmpc.set_reference(list(g["refs"][i]), i)
+for k in range(len(g["u"])):
+    nmpc.prepare()
+    nmpc.set_wind_velocity(list(g["winds"][k]))
+    nmpc.solve(list(g["meas"][k]))
+    u, st = nmpc.get_result()
+    assert nmpc.get_controls() == u
+    assert st == g["status"][k], (k, st)
+    assert np.array_equal(np.array(u), g["u"][k]), (k, u, g["u"][k])
+    nmpc.update_horizon(list(g["refs"][101 + k]))
+# plant integration (c/cnmpc.cpp:173-180) against the golden RK4 vectors
+m = golden("model")
+for i in range(5):
+    nmpc.set_wind_velocity(list(m["wind"][i]))
+    s = nmpc.state
+    s.position[:] = list(m["x"][i, 0:3]); s.velocity[:] = list(m["x"][i, 3:6])
+    s.attitude[:] = list(m["x"][i, 6:10]); s.angular_velocity[:] = list(m["x"][i, 10:13])
+    nmpc.integrate(0.02, list(m["u"][i]))
+    got = np.array(list(s.position) + list(s.velocity) + list(s.attitude) + list(s.angular_velocity))
+    # dt crosses the ABI as a C float (c/cnmpc.h:84): 0.02f != 1/50, so compare
+    # against an RK4 step of exactly that length
+    from nmpc_amd.batch import rk4_samples
+    exp = rk4_samples(m["x"][i:i+1], m["u"][i:i+1], m["wind"][i:i+1], delta=float(np.float32(0.02)))[0]
+    assert np.array_equal(got, exp), (i, got, exp)
+print("child ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
+
+
+def _port_cold(d, N, threads=16):
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    cfg = S.setup_args()
+    return P.batch_cold_solve(
+        N, cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+        cfg["lower_control_bound"], cfg["upper_control_bound"], d["refs"][:, :N + 1],
+        d["meas"][:, 0], d["wind"], threads=threads)
+
+
+def _gpu_cold(d, N):
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    B = d["refs"].shape[0]
+    bt = Batch(B, N)
+    bt.setup(**S.setup_args())
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    bt.solve(d["meas"][:, 0])
+    out = bt.get_controls()
+    return bt, out
+
+
+def test_full_size_cold_solve_4096(port_built):
+    """The benchmark configuration (4096 instances, horizon 100): every
+    instance against the CPU oracle, plus a permutation property."""
+    from nmpc_amd import synthetic as S
+    N, B = 100, 4096
+    d = S.make_batch(B, N, seed=S.DEFAULT_SEED)
+    bt, (u, st, it) = _gpu_cold(d, N)
+    eu, est, eit, _ = _port_cold(d, N)
+    assert_same(st, est, "status")
+    assert_same(it, eit, "QP iterations")
+    assert_same(u, eu, "controls")
+    assert (st == 0).sum() > B // 2
+    bt.close()
+    # reversed instance order gives the reversed result
+    dr = {k: np.ascontiguousarray(v[::-1]) for k, v in d.items()}
+    bt2, (u2, st2, it2) = _gpu_cold(dr, N)
+    assert_same(u2[::-1], u, "controls under instance permutation")
+    assert_same(it2[::-1], it, "iterations under instance permutation")
+    bt2.close()
+
+
+def test_long_horizon_batch(port_built):
+    """Horizon 500 (stage-parallel QP work): 24 instances against the oracle."""
+    from nmpc_amd import synthetic as S
+    N, B = 500, 24
+    d = S.make_batch(B, N, seed=8, turn_start=(0.3, 9.0))
+    bt, (u, st, it) = _gpu_cold(d, N)
+    eu, est, eit, _ = _port_cold(d, N)
+    assert_same(st, est, "status")
+    assert_same(it, eit, "QP iterations")
+    assert_same(u, eu, "controls")
+    bt.close()
+
+
+def test_small_and_odd_shapes(port_built):
+    """Shapes that leave wavefronts partly empty: 3 instances x 7 stages,
+    1 instance x 2 stages."""
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    for B, N, steps in ((3, 7, 6), (1, 2, 4), (5, 65, 3)):
+        d = S.make_batch(B, N, extra_steps=steps, seed=B * 100 + N, turn_start=(0.05, 0.5))
+        gs = []
+        cfg = S.setup_args()
+        for b in range(B):
+            gs.append(dict(horizon=np.int32(N), refs=d["refs"][b], meas=d["meas"][b],
+                           winds=np.tile(d["wind"][b], (steps, 1)), u=np.zeros((steps, 3)),
+                           state_weights=np.array(cfg["state_weights"], float),
+                           control_weights=np.array(cfg["control_weights"], float),
+                           terminal_weights=np.array(cfg["terminal_weights"], float),
+                           upper=np.array(cfg["upper_control_bound"], float),
+                           lower=np.array(cfg["lower_control_bound"], float)))
+        out = drive_gpu_batch(gs, dump=True)
+        from helpers import drive_port
+        for b in range(B):
+            exp = drive_port(gs[b], dump=True)
+            tag = "B%d N%d inst %d " % (B, N, b)
+            assert_same(out["status"][b], exp["status"], tag + "status")
+            assert_same(out["iters"][b], exp["iters"], tag + "iterations")
+            assert_same(out["u"][b], exp["u"], tag + "controls")
+            assert_same(out["final_stages"][b], exp["final_stages"], tag + "stage records")
+            assert_same(out["final_globals"][b], exp["final_globals"], tag + "solver state")
+
+
+def test_million_sample_linearisation(port_built):
+    """2^20 (x, u, wind) samples through the stage-linearisation kernel:
+    a strided subset against the oracle and batch-position independence."""
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import linearise_samples
+    n = 1 << 20
+    rng = np.random.default_rng(5)
+    x, u, w = S.random_states(n, rng)
+    xn = np.roll(x, 1, axis=0)
+    lo, up = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    jac, res = linearise_samples(x, u, xn, w, lo, up)
+    for i in range(0, n, 4099):
+        ej, er = P.linearise(x[i], u[i], xn[i], w[i], lo, up)
+        assert_same(jac[i], ej, "Jacobian sample %d" % i)
+        assert_same(res[i], er, "residual sample %d" % i)
+    perm = rng.permutation(n)[: 1 << 16]
+    j2, r2 = linearise_samples(x[perm], u[perm], xn[perm], w[perm], lo, up)
+    assert_same(j2, jac[perm], "Jacobian under permutation")
+    assert_same(r2, res[perm], "residual under permutation")
+
+
+def test_device_resident_inputs_match_host_inputs():
+    """torch CUDA tensors are consumed in place and give the same results."""
+    import torch
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B = 100, 64
+    d = S.make_batch(B, N, extra_steps=2, seed=21)
+    _, (u, st, it) = _gpu_cold(d, N)
+    dev = torch.device("cuda:0")
+    bt = Batch(B, N, stream=torch.cuda.current_stream().cuda_stream)
+    bt.setup(**S.setup_args())
+    bt.initialise_horizon()
+    bt.set_wind_velocity(torch.from_numpy(d["wind"]).to(dev))
+    bt.set_reference(torch.from_numpy(np.ascontiguousarray(d["refs"][:, :N + 1])).to(dev))
+    bt.solve(torch.from_numpy(np.ascontiguousarray(d["meas"][:, 0])).to(dev))
+    tu = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    ts = torch.zeros(B, dtype=torch.int32, device=dev)
+    ti = torch.zeros(B, dtype=torch.int32, device=dev)
+    bt.get_controls_into(tu, ts, ti)
+    assert_same(tu.cpu().numpy(), u, "controls")
+    assert_same(ts.cpu().numpy(), st, "status")
+    assert_same(ti.cpu().numpy(), it, "iterations")
+    bt.close()
+
+
+def test_error_reporting():
+    from nmpc_amd import _lib
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    bt = Batch(2, 10)
+    with pytest.raises(_lib.NmpcError):
+        bt.solve(np.zeros((2, 13)))             # before initialise_horizon
+    bt.setup(**S.setup_args())
+    bt.initialise_horizon()
+    with pytest.raises(_lib.NmpcError):
+        bt.set_reference(np.zeros((2, 3, 16)), first=9)     # runs past the horizon
+    with pytest.raises(ValueError):
+        bt.set_wind_velocity(np.zeros((3, 3)))
+    bt.close()
+    h = ctypes.c_void_p()
+    lib = _lib.load()
+    assert lib.nmpc_batch_create(ctypes.byref(h), 1, 100, 99, None) == -1   # no such device
+
+
+def test_kernel_timing_interface():
+    from nmpc_amd import synthetic as S
+    N, B = 100, 128
+    d = S.make_batch(B, N, seed=2)
+    from nmpc_amd.batch import Batch
+    bt = Batch(B, N)
+    bt.setup(**S.setup_args())
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.set_profiling(True)
+    bt.set_reference(d["refs"][:, :N + 1])
+    bt.solve(d["meas"][:, 0])
+    t = bt.kernel_times()
+    assert t["linearise"][1] == 1 and t["linearise"][0] > 0
+    assert t["newton_solve"][1] == 5 and t["qp_begin"][1] == 1
+    bt.close()

@@ -1,0 +1,131 @@
+"""CPU tests: the oracle port (oracle/nmpc_port.c) against the golden vectors
+generated from the compiled reference (tests/golden/generate.py), and against
+the compiled reference itself where oracle/_ref is present."""
+import numpy as np
+import pytest
+
+from helpers import SEQUENCES, assert_same, drive_port, golden
+
+
+def test_model_functions(port_built):
+    P = port_built
+    g = golden("model")
+    n = len(g["x"])
+    for i in range(n):
+        assert_same(P.x8_dynamics(g["x"][i], g["u"][i], g["wind"][i]), g["accel"][i], "accel[%d]" % i)
+        assert_same(P.state_model(g["x"][i], g["u"][i], g["wind"][i]), g["xdot"][i], "xdot[%d]" % i)
+        assert_same(P.rk4(g["x"][i], g["u"][i], g["wind"][i]), g["xplus"][i], "xplus[%d]" % i)
+        assert_same(P.state_to_delta(g["s1"][i], g["s2"][i]), g["delta"][i], "delta[%d]" % i)
+
+
+def test_model_covers_branches():
+    """The fixture reaches both stall blends, the thrust clamp and the airspeed floors."""
+    g = golden("model")
+    x, u, w = g["x"], g["u"], g["wind"]
+    assert (u[:, 0] < 0).any() and (u[:, 0] > 1).any()
+    rel = w - x[:, 3:6]
+    speed = np.linalg.norm(rel, axis=1)
+    assert (speed < 1.0).any() and (speed == 0.0).any() and (speed > 20).any()
+    # error quaternions with negative real part exist
+    s1, s2 = g["s1"], g["s2"]
+    dots = np.sum(s1[:, 6:10] * s2[:, 6:10], axis=1)
+    assert (dots < 0).any() and (dots > 0).any()
+
+
+def test_linearise(port_built):
+    P = port_built
+    g = golden("linearise")
+    for i in range(len(g["x"])):
+        jac, res = P.linearise(g["x"][i], g["u"][i], g["xnext"][i], g["wind"][i],
+                               g["lower"], g["upper"])
+        assert_same(jac, g["jac"][i], "jac[%d]" % i)
+        assert_same(res, g["res"][i], "res[%d]" % i)
+
+
+@pytest.mark.parametrize("name", SEQUENCES)
+def test_sequences(port_built, name):
+    g = golden(name)
+    dump = "final_stages" in g
+    out = drive_port(g, dump=dump)
+    assert_same(out["status"], g["status"], name + " status")
+    assert_same(out["iters"], g["iters"], name + " iterations")
+    assert_same(out["u"], g["u"], name + " controls")
+    assert_same(out["z0"], g["z0"], name + " z0")
+    if dump:
+        assert_same(out["loaded_Cc"], g["loaded_Cc"], name + " C,c after loading")
+        assert_same(out["final_stages"], g["final_stages"], name + " final stage records")
+        assert_same(out["final_globals"], g["final_globals"], name + " final solver state")
+
+
+def test_known_answer_straight():
+    """Controls of the level-flight scenario as recorded, to 12 digits, from an
+    independently compiled fp64 build of the reference (different compiler
+    flags from oracle/Makefile, hence the 1e-9 relative bar rather than bit
+    equality) -- guards the fixture generator itself."""
+    g = golden("seq_straight")
+    expect = [(0.723136204856, 0.482301597738, 0.499387321079, 3),
+              (0.723138101354, 0.482302017451, 0.499386802355, 2),
+              (0.723138017347, 0.482302031, 0.49938678338, 2),
+              (0.723139840814, 0.482302464467, 0.499386245191, 2)]
+    for k, (a, b, c, it) in enumerate(expect):
+        np.testing.assert_allclose(g["u"][k], [a, b, c], rtol=1e-9, atol=0)
+        assert g["iters"][k] == it
+
+
+def test_port_against_compiled_reference(port_built):
+    """Where the reference build exists (this container), replay fresh random
+    sequences through both and compare every stored quantity."""
+    import refdriver
+    if not refdriver.have_ref(100):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    from nmpc_amd import synthetic as S
+    P = port_built
+    N, steps = 100, 12
+    d = S.make_batch(3, N, extra_steps=steps, seed=77, turn_start=(0.3, 3.0))
+    cfg = S.setup_args()
+    for b in range(3):
+        r, p = refdriver.Ref(N), P.Port(N)
+        for o in (r, p):
+            o.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                    cfg["upper_control_bound"], cfg["lower_control_bound"])
+            o.init()
+            o.set_wind(d["wind"][b])
+            for i in range(N + 1):
+                o.set_reference(d["refs"][b, i], i)
+        for k in range(steps):
+            for o in (r, p):
+                o.feedback(d["meas"][b, k])
+            (ur, sr), (up, sp) = r.controls(), p.controls()
+            assert_same(up, ur, "controls b%d k%d" % (b, k))
+            assert sr == sp and r.num_iter() == p.num_iter()
+            assert_same(p.stages(), r.stages(), "stages b%d k%d" % (b, k))
+            assert_same(p.globals_(), r.globals_(), "globals b%d k%d" % (b, k))
+            for o in (r, p):
+                o.update_horizon(d["refs"][b, N + 1 + k])
+
+
+def test_batch_driver_matches_single(port_built):
+    """The threaded cold-solve driver used as CPU baseline gives the same
+    answers as driving instances one by one."""
+    from nmpc_amd import synthetic as S
+    P = port_built
+    N, B = 100, 6
+    d = S.make_batch(B, N, seed=123, turn_start=(0.3, 3.0))
+    cfg = S.setup_args()
+    u, st, it, secs = P.batch_cold_solve(
+        N, cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+        cfg["lower_control_bound"], cfg["upper_control_bound"], d["refs"], d["meas"][:, 0],
+        d["wind"], threads=3)
+    assert secs > 0
+    for b in range(B):
+        p = P.Port(N)
+        p.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        p.init()
+        p.set_wind(d["wind"][b])
+        for i in range(N + 1):
+            p.set_reference(d["refs"][b, i], i)
+        p.feedback(d["meas"][b, 0])
+        eu, es = p.controls()
+        assert_same(u[b], eu, "controls %d" % b)
+        assert st[b] == es and it[b] == p.num_iter()
