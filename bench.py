@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched NMPC hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--instances B] [--horizon H]
+
+One step = one cold solve of a batch of B independent controllers, i.e. the
+reference's start-up sequence per controller (state reset, nmpc_init, wind,
+H+1 reference points -- which runs the RK4 + finite-difference linearisation
+of every horizon stage -- one feedback step, get controls), with all inputs
+already resident in HBM.  Default workload: 4096 instances, horizon 100, fp64.
+With --gpus N > 1 (launched through torch.distributed.run) every rank owns B
+instances on its own GPU (weak scaling) and the per-step results are
+all-gathered over RCCL.
+
+Prints one JSON line on rank 0.  Besides the whole-job rate it carries
+  roofline      the dominant kernel's algorithmic HBM bytes per launch over its
+                mean launch duration, measured with HIP events on the stream
+                the kernels run on, during the timed steps
+  cpu_baseline  the CPU oracle port (oracle/nmpc_port.c, a restatement of the
+                reference's pure-C path, bit-identical to it) on the same
+                inputs, threaded over the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before libcnmpc.so: see nmpc_amd/_lib.py)
+
+from nmpc_amd import synthetic as S  # noqa: E402
+from nmpc_amd.batch import Batch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, spec
+FP64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector, spec (FMA counted as 2 flop)
+
+# Algorithmic work per unit, from the operation counts of the reference
+# functions (one flop per add/sub/mul/div/sqrt/compare-select):
+#   linearise     per stage: 16 RK4 integrations + 16 state differences;
+#                 reads x_k, u_k (128 B), writes C (1440 B) and c (96 B)
+#   newton_solve  per stage block and Newton iteration: reverse Cholesky of a
+#                 12x12 diagonal + 12x12 sub-diagonal block (4.2 kflop) and two
+#                 substitutions (0.84 kflop); reads the Hessian block row
+#                 (2304 B) and the gradient (96 B), writes the factor (2304 B)
+#                 and the step (96 B)
+#   newton_setup  per stage and iteration: gradient (0.38 kflop) + Hessian
+#                 blocks (4.7 kflop); reads C, c, z, y (1896 B), writes the
+#                 block row and gradient (2400 B)
+#   newton_step / qp_begin  per stage and call: stage update, clipping,
+#                 objective; reads C, c and the 15-vectors, writes them back
+ALGO = {
+    "linearise": dict(flop=17000.0, bytes=1664.0),
+    "newton_solve": dict(flop=5040.0, bytes=4800.0),
+    "newton_setup": dict(flop=5080.0, bytes=4296.0),
+    "newton_step": dict(flop=670.0, bytes=3100.0),
+    "qp_begin": dict(flop=260.0, bytes=1100.0),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--instances", type=int, default=4096, help="controller instances per GPU")
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=S.DEFAULT_SEED)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096,
+                    help="instances of the workload the CPU baseline solves")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                     % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, N = a.instances, a.horizon
+    # every rank draws its own instances: seed + rank
+    d = S.make_batch(B, N, seed=a.seed + rank)
+    refs = torch.from_numpy(np.ascontiguousarray(d["refs"][:, :N + 1])).to(dev)
+    meas = torch.from_numpy(np.ascontiguousarray(d["meas"][:, 0])).to(dev)
+    wind = torch.from_numpy(d["wind"]).to(dev)
+    out_u = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    out_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    out_it = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    stream = torch.cuda.current_stream(dev)
+    bt = Batch(B, N, device=local, stream=stream.cuda_stream)
+    bt.setup(**S.setup_args())
+
+    if world > 1:
+        from nmpc_amd import sharding
+
+    def step():
+        bt.reset()
+        bt.initialise_horizon()
+        bt.set_wind_velocity(wind)
+        bt.set_reference(refs)
+        bt.prepare()
+        bt.solve(meas)
+        bt.get_controls_into(out_u, out_st, out_it)
+        if world > 1:
+            return sharding.gather_results(out_u, out_st, out_it)
+        return out_u, out_st, out_it
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    bt.set_profiling(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    marks[0].record(stream)
+    for k in range(a.steps):
+        res = step()
+        marks[k + 1].record(stream)
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ktimes = bt.kernel_times()
+    bt.set_profiling(False)
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
+    u_all, st_all, it_all = (x.cpu().numpy() for x in res)
+    u, st, it = out_u.cpu().numpy(), out_st.cpu().numpy(), out_it.cpu().numpy()
+
+    total_instances = B * world
+    value = total_instances * a.steps / elapsed
+
+    # ---- roofline of the dominant kernel (rank 0's GPU) ----------------------
+    # units each launch kind processed over the timed steps
+    newton_runs = np.where(st == 0, it - 1, it).astype(np.int64)    # factor/step executions
+    setup_runs = it.astype(np.int64)                                # gradient evaluations
+    units = {
+        "linearise": B * N * a.steps,
+        "qp_begin": B * (N + 1) * a.steps,
+        "newton_setup": int(setup_runs.sum()) * N * a.steps,
+        "newton_solve": int(newton_runs.sum()) * N * a.steps,
+        "newton_step": int(newton_runs.sum()) * (N + 1) * a.steps,
+    }
+    kern = {}
+    for name, (ms, n) in ktimes.items():
+        if n == 0 or name not in ALGO:
+            continue
+        gb = ALGO[name]["bytes"] * units[name] / 1e9
+        tf = ALGO[name]["flop"] * units[name] / 1e12
+        kern[name] = dict(total_ms=round(ms, 3), launches=int(n), avg_ms=round(ms / n, 4),
+                          algo_GBps=round(gb / (ms / 1e3), 1), algo_TFLOPs=round(tf / (ms / 1e3), 3))
+    dominant = max(kern, key=lambda k: kern[k]["total_ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("instances") == B and tj.get("horizon") == N:
+            traffic = tj.get("bytes_per_launch", {}).get(dominant)
+    achieved = kern[dominant]["algo_GBps"]
+    roofline = dict(kernel=dominant, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    avg_launch_ms=kern[dominant]["avg_ms"],
+                    algo_bytes_per_launch=round(ALGO[dominant]["bytes"] * units[dominant]
+                                                / max(1, kern[dominant]["launches"])),
+                    fp64_vector_frac=round(kern[dominant]["algo_TFLOPs"] / FP64_VECTOR_PEAK_TF, 5))
+
+    # ---- CPU baseline (rank 0, N=1 only) -------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import portdriver as P
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        n = min(a.cpu_sample, B)
+        cfg = S.setup_args()
+        cu, cst, cit, secs = P.batch_cold_solve(
+            N, cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+            cfg["lower_control_bound"], cfg["upper_control_bound"], d["refs"][:n, :N + 1],
+            d["meas"][:n, 0], d["wind"][:n], threads=cores)
+        parity = bool(np.array_equal(cu, u[:n]) and np.array_equal(cst, st[:n])
+                      and np.array_equal(cit, it[:n]))
+        cpu = dict(value=round(n / secs, 1), unit="solves/s", cores=cores, kind="port",
+                   sample="first %d instances of the same workload, cold solve each, "
+                          "%.2f s wall" % (n, secs),
+                   gpu_results_identical=parity)
+
+    if rank == 0:
+        line = {
+            "metric": "NMPC solves/sec (prep+feedback) at batch B, default horizon",
+            "value": round(value, 1), "unit": "solves/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "p50_step_ms": round(step_ms[len(step_ms) // 2], 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d independent UAV NMPC instances per GPU, horizon %d, "
+                                   "cold solve (reset, init, %d reference points = all stages "
+                                   "linearised, feedback, get controls), fp64"
+                                   % (B, N, N + 1),
+                       "instances_per_gpu": B, "horizon": N, "total_instances": total_instances,
+                       "parallelism": "instance partition, %d GPU(s)" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kern,
+            "solver": {"converged_frac": round(float((st_all == 0).mean()), 4),
+                       "mean_qp_iterations": round(float(it_all.mean()), 3)},
+        }
+        print(json.dumps(line))
+    bt.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,12 @@ int nmpc_batch_create(nmpc_batch_t **out, uint32_t instances, uint32_t horizon,
                       int device, void *stream);
 int nmpc_batch_destroy(nmpc_batch_t *b);
 int nmpc_batch_synchronize(nmpc_batch_t *b);
+/* Back to the state right after nmpc_batch_create (multipliers, stage
+ * variables, references, wind, results all zero; weights and bounds kept), so
+ * that the next nmpc_batch_init + reference loading is a cold start.  The
+ * Jacobian and Newton-system storage is not cleared: nmpc_batch_init zeroes
+ * the former and the first solve rebuilds the latter in full.  Asynchronous. */
+int nmpc_batch_reset(nmpc_batch_t *b);
 
 /* nmpc_set_*_weights / nmpc_set_*_control_bound for every instance
  * (ccs-c66x/cnmpc.c:988-1020).  Host pointers. */

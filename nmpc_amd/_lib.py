@@ -66,6 +66,7 @@ PROTOTYPES = {
                                     C.c_int, C.c_void_p]),
     "nmpc_batch_destroy": (C.c_int, [C.c_void_p]),
     "nmpc_batch_synchronize": (C.c_int, [C.c_void_p]),
+    "nmpc_batch_reset": (C.c_int, [C.c_void_p]),
     "nmpc_batch_set_state_weights": (C.c_int, [C.c_void_p, PREAL]),
     "nmpc_batch_set_control_weights": (C.c_int, [C.c_void_p, PREAL]),
     "nmpc_batch_set_terminal_weights": (C.c_int, [C.c_void_p, PREAL]),

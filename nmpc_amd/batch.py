@@ -128,6 +128,10 @@ class Batch:
         self._ck(self.lib.nmpc_batch_update_horizon(self.h, a.ptr))
         self._keep.append(a)
 
+    def reset(self):
+        """Cold-start state again (see nmpc_batch_reset); weights and bounds stay."""
+        self._ck(self.lib.nmpc_batch_reset(self.h))
+
     def synchronize(self):
         self._ck(self.lib.nmpc_batch_synchronize(self.h))
         self._keep = []

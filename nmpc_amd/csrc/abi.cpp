@@ -88,6 +88,7 @@ struct nmpc_batch {
     BatchView v{};
     void* arena = nullptr;
     size_t arena_bytes = 0;
+    size_t reset_bytes = 0;     // leading part of the arena that nmpc_batch_reset clears
     double wq[12], wr[3], wt[12], lb[3], ub[3];
     bool initialised = false;
     Staging in_refs, in_meas, in_wind, out_u, out_status, out_iters, scratch;
@@ -197,10 +198,11 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
 
     struct Field { void** p; size_t bytes; };
     const size_t d = sizeof(double);
+    // The last three fields are rebuilt in full by nmpc_batch_init (C) and by
+    // the first solve after it (hess, chol); nmpc_batch_reset skips them.
     Field fields[] = {
         {(void**)&v.xref, B * N1 * 13 * d}, {(void**)&v.uref, B * N * 3 * d},
-        {(void**)&v.wind, B * 3 * d},
-        {(void**)&v.C, B * N * 180 * d},    {(void**)&v.c, B * N * 12 * d},
+        {(void**)&v.wind, B * 3 * d},       {(void**)&v.c, B * N * 12 * d},
         {(void**)&v.zLow, B * N1 * 15 * d}, {(void**)&v.zUpp, B * N1 * 15 * d},
         {(void**)&v.q, B * N1 * 15 * d},    {(void**)&v.z, B * N1 * 15 * d},
         {(void**)&v.qStep, B * N1 * 15 * d},{(void**)&v.zUnc, B * N1 * 15 * d},
@@ -208,12 +210,17 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
         {(void**)&v.y, B * N1 * 30 * d},    {(void**)&v.p, B * N1 * d},
         {(void**)&v.pStep, B * N1 * d},     {(void**)&v.lam, B * N * 12 * d},
         {(void**)&v.dl, B * N * 12 * d},    {(void**)&v.grad, B * N * 12 * d},
-        {(void**)&v.hess, B * N * 288 * d}, {(void**)&v.chol, B * N * 288 * d},
         {(void**)&v.ieq, B * N1 * 15},      {(void**)&v.prev, B * N1 * 15},
         {(void**)&v.chg, B * N1},           {(void**)&v.sc, B * sizeof(Scalars)},
+        {(void**)&v.C, B * N * 180 * d},
+        {(void**)&v.hess, B * N * 288 * d}, {(void**)&v.chol, B * N * 288 * d},
     };
     size_t total = 0;
-    for (auto& f : fields) total += align_up(f.bytes);
+    const size_t n_fields = sizeof fields / sizeof fields[0];
+    for (size_t i = 0; i < n_fields; i++) {
+        if (i == n_fields - 3) b->reset_bytes = total;
+        total += align_up(fields[i].bytes);
+    }
     hipError_t e = hipMalloc(&b->arena, total);
     if (e != hipSuccess) {
         if (b->own_stream) (void)hipStreamDestroy(b->stream);
@@ -251,6 +258,15 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
     if (b->arena) (void)hipFree(b->arena);
     if (b->own_stream) (void)hipStreamDestroy(b->stream);
     delete b;
+    return 0;
+}
+
+int nmpc_batch_reset(nmpc_batch_t* b) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    TRY(use_device(b));
+    HIP_TRY(hipMemsetAsync(b->arena, 0, b->reset_bytes, b->stream));
+    b->v.head = b->v.xhead = b->v.lhead = 0;
+    b->initialised = false;
     return 0;
 }
 

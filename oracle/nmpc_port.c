@@ -84,6 +84,7 @@ struct port_s {
     int *ieq, *prev;            /* (N+1) x 15 */
     double alpha;
     int numIter, lastResult, lastStatus, lsIter, regularized;
+    int nBacktrack, nBisect, nFullStep;   /* per-solve trial counters (diagnostics) */
     double u[NU];
 };
 
@@ -702,6 +703,7 @@ static int backtracking(port_t *p, double *alpha, int *it, double alphaMax,
     *alpha = alphaMax;
     for (; *it < OPT_MAX_LS_ITER; ++(*it)) {
         double obj = trial_objective(p, *alpha);
+        p->nBacktrack++;
         if (obj > objInc + minProg) return ST_OK;
         *alpha = (*alpha) * OPT_LS_REDUCTION;
         if (nrm * (*alpha - 0.) < OPT_EQ_TOL) { *alpha = 0.; return ST_LS_MIN_STEP; }
@@ -732,6 +734,7 @@ static int bisection(port_t *p, double *alpha, int *it, double alphaMin,
     double normal = (1. < nd) ? 1. : nd;
     for (; *it < OPT_MAX_LS_REFINE; ++(*it)) {
         slope = trial_slope(p, alphaMax);
+        p->nBisect++;
         if (fabs(slope / normal) <= OPT_LS_STAT_TOL) { *alpha = alphaMax; return ST_OK; }
         if (slope / normal < 0.) break;
         alphaMin = alphaMax;
@@ -741,6 +744,7 @@ static int bisection(port_t *p, double *alpha, int *it, double alphaMin,
     for (; *it < OPT_MAX_LS_REFINE; ++(*it)) {
         alphaC = 0.5 * (alphaMin + alphaMax);
         slope = trial_slope(p, alphaC);
+        p->nBisect++;
         if (fabs(slope / normal) <= OPT_LS_STAT_TOL) { *alpha = alphaC; return ST_OK; }
         if (slope > 0) alphaMin = alphaC; else alphaMax = alphaC;
     }
@@ -763,6 +767,7 @@ static int step_length(port_t *p, double *objInc) {
     }
     if (alphaMin > 1. - OPT_EQ_TOL && !p->regularized) {
         p->alpha = 1.;
+        p->nFullStep++;
         for (int i = 0; i < n; i++) p->lambda[i] = p->lambda[i] + p->alpha * p->dlambda[i];
         for (int k = 0; k <= N; k++) stage_step(stage_at(p, k), p->alpha);
         *objInc = objective(p);
@@ -788,6 +793,7 @@ static int dual_newton_solve(port_t *p) {
     int N = p->N, last, st;
     double objInc;
     p->numIter = 0;
+    p->nBacktrack = p->nBisect = p->nFullStep = 0;
     for (int k = 0; k <= N; k++) stage_step(stage_at(p, k), 1);
     objInc = objective(p);
     active_set(p);
@@ -858,6 +864,9 @@ int port_last_status(const port_t *p) { return p->lastStatus; }
 double port_alpha(const port_t *p) { return p->alpha; }
 int port_line_search_iter(const port_t *p) { return p->lsIter; }
 int port_hessian_regularized(const port_t *p) { return p->regularized; }
+void port_trial_counts(const port_t *p, int *out3) {
+    out3[0] = p->nBacktrack; out3[1] = p->nBisect; out3[2] = p->nFullStep;
+}
 
 void port_get_stage(const port_t *p, unsigned k, double *o) {
     const stage_t *s = stage_at(p, (int)k);

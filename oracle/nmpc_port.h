@@ -46,6 +46,8 @@ int port_last_status(const port_t *p);           /* internal solver status */
 double port_alpha(const port_t *p);
 int port_line_search_iter(const port_t *p);
 int port_hessian_regularized(const port_t *p);
+/* backtracking trials, bisection trials, full steps of the last solve */
+void port_trial_counts(const port_t *p, int *out3);
 void port_get_stage(const port_t *p, unsigned k, double *out332);
 unsigned port_global_size(const port_t *p);
 void port_get_global(const port_t *p, double *out);
