@@ -1,0 +1,396 @@
+// Stage-parallel half of the dual Newton solve: one 256-thread workgroup per
+// controller instance.
+//
+//   k_qp_begin     initial-value embedding and the opening step
+//                  (ccs-c66x/cnmpc.c:675-702, qpDUNES/dual_qp.c:56-100)
+//   k_newton_step  stage directions for the multiplier step, step-length
+//                  selection (full step / backtracking / gradient bisection),
+//                  commit, active-set bookkeeping
+//                  (dual_qp.c:309-379, 1119-1470, 1542-1699;
+//                   stage_qp_solver_clipping.c:42-198)
+//
+// Element-wise stage work (step, clip, gaps, linear term) runs over the flat
+// slot-ordered index e = 15 slot + i, so global accesses are contiguous across
+// lanes; the clipped primal and linear term of 64 stages at a time are kept in
+// LDS for the per-stage objective values.  Every sum whose order the reference
+// fixes (objective over stages, norms and slopes over multiplier rows) is
+// produced in parallel and accumulated in index order by one wavefront.
+// All control flow depends only on per-instance values, so it is uniform over
+// the workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+#include "qp_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace nmpc {
+
+namespace {
+
+constexpr int kStageThreads = 256;
+constexpr int kStageChunk = 64;                 // stage slots whose z, q sit in LDS at once
+constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920: z + q, reused as sum buffer
+
+// dynamic LDS: buf[1920] | vals[N+1] | red[8] | chg[N+1] (int)
+struct StageLds {
+    double* z;      // [64*15]
+    double* q;      // [64*15]
+    double* buf;    // = z, 1920 doubles for ordered sums
+    double* vals;   // [N+1] stage objective values by slot
+    double* red;    // [8]
+    int* chg;       // [N+1] active set of slot changed
+};
+
+NMPC_DEV StageLds carve(double* base, int N) {
+    StageLds L;
+    L.z = base;
+    L.q = base + kStageChunk * NZ;
+    L.buf = base;
+    L.vals = base + kBufDoubles;
+    L.red = L.vals + (N + 1);
+    L.chg = (int*)(L.red + 8);
+    return L;
+}
+
+inline size_t stage_lds_bytes(int N) {
+    return (size_t)(kBufDoubles + (N + 1) + 8) * sizeof(double) + (size_t)(N + 1) * sizeof(int);
+}
+
+// acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order.  The
+// LDS reads of the next eight values are issued before the current eight are
+// added, so the loop runs at the latency of the dependent adds.
+NMPC_DEV double accumulate_in_order(double acc, const double* buf, int len) {
+    int t = 0;
+    if (len >= 8) {
+        double c0 = buf[0], c1 = buf[1], c2 = buf[2], c3 = buf[3];
+        double c4 = buf[4], c5 = buf[5], c6 = buf[6], c7 = buf[7];
+        for (t = 8; t + 8 <= len; t += 8) {
+            const double n0 = buf[t], n1 = buf[t + 1], n2 = buf[t + 2], n3 = buf[t + 3];
+            const double n4 = buf[t + 4], n5 = buf[t + 5], n6 = buf[t + 6], n7 = buf[t + 7];
+            acc += c0; acc += c1; acc += c2; acc += c3;
+            acc += c4; acc += c5; acc += c6; acc += c7;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5; c6 = n6; c7 = n7;
+        }
+        acc += c0; acc += c1; acc += c2; acc += c3;
+        acc += c4; acc += c5; acc += c6; acc += c7;
+    }
+    for (; t < len; t++) acc += buf[t];
+    return acc;
+}
+
+// Sum term(0) + ... + term(n-1) in index order starting from 0.  Terms are
+// produced by all threads; wavefront 0 accumulates.  Uniform result.
+template <class F>
+NMPC_DEV double block_ordered_sum(int n, const StageLds& L, F term) {
+    const int tid = threadIdx.x;
+    double acc = 0.;
+    for (int base = 0; base < n; base += kBufDoubles) {
+        const int len = (n - base < kBufDoubles) ? n - base : kBufDoubles;
+        int r = tid;
+        for (; r + kStageThreads < len; r += 2 * kStageThreads) {   // two terms in flight
+            const double t0 = term(base + r);
+            const double t1 = term(base + r + kStageThreads);
+            L.buf[r] = t0;
+            L.buf[r + kStageThreads] = t1;
+        }
+        if (r < len) L.buf[r] = term(base + r);
+        __syncthreads();
+        if (tid < kWave) acc = accumulate_in_order(acc, L.buf, len);
+        __syncthreads();
+    }
+    if (tid == 0) L.red[0] = acc;
+    __syncthreads();
+    const double out = L.red[0];
+    __syncthreads();
+    return out;
+}
+
+NMPC_DEV double block_min(double x, const StageLds& L) {
+    x = wave_min(x);
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) L.red[1 + (tid >> 6)] = x;
+    __syncthreads();
+    double m = L.red[1];
+#pragma unroll
+    for (int w = 1; w < kStageThreads / kWave; w++) m = (L.red[1 + w] < m) ? L.red[1 + w] : m;
+    __syncthreads();
+    return m;
+}
+
+NMPC_DEV int block_max(int x, const StageLds& L) {
+    x = wave_max(x);
+    const int tid = threadIdx.x;
+    int* r = (int*)(L.red + 5);
+    if ((tid & 63) == 0) r[tid >> 6] = x;
+    __syncthreads();
+    int m = r[0];
+#pragma unroll
+    for (int w = 1; w < kStageThreads / kWave; w++) m = (r[w] > m) ? r[w] : m;
+    __syncthreads();
+    return m;
+}
+
+enum PassMode { kBegin, kCommit, kTrialValue, kTrialPoint };
+
+// One pass over every stage at step length a.
+//   kBegin / kCommit  apply the step (stage_qp_solver_clipping.c:134-165), refresh the
+//                     active-set record (dual_qp.c:1627-1699); returns the objective
+//                     (dual_qp.c:1542-1566)
+//   kTrialValue       objective at a trial step; only z and y are overwritten
+//                     (dual_qp.c:1574-1617)
+//   kTrialPoint       clipped trial point into tmp, gaps into y (dual_qp.c:1370-1376);
+//                     returns 0
+template <PassMode MODE>
+NMPC_DEV double stage_pass(const BatchView& v, const Inst& I, double a, const StageLds& L) {
+    const int tid = threadIdx.x, N = v.N;
+    const int eEnd = NZ * N + NX;            // terminal slot holds 12 variables
+    for (int c0 = 0; c0 <= N; c0 += kStageChunk) {
+        const int c1 = (c0 + kStageChunk <= N + 1) ? c0 + kStageChunk : N + 1;
+        const int e0 = c0 * NZ;
+        const int e1 = (c1 * NZ < eEnd) ? c1 * NZ : eEnd;
+        for (int e = e0 + tid; e < e1; e += kStageThreads) {
+            const double zu = I.zUnc[e] + a * I.dz[e];
+            if (MODE == kBegin || MODE == kCommit) I.zUnc[e] = zu;
+            double y0, y1;
+            const double zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
+            I.y[2 * e] = y0;
+            I.y[2 * e + 1] = y1;
+            if (MODE == kTrialPoint) {
+                I.tmp[e] = zc;
+            } else {
+                I.z[e] = zc;
+                const double qv = I.q[e] + a * I.qStep[e];
+                if (MODE != kTrialValue) I.q[e] = qv;
+                L.z[e - e0] = zc;
+                L.q[e - e0] = qv;
+            }
+            if (MODE == kBegin || MODE == kCommit) {
+                const int s = e / NZ, i = e - s * NZ;
+                const int idx = slot_position(v, s) * NZ + i;
+                const int8_t code = (y0 > kEqTol) ? -1 : ((y1 > kEqTol) ? 1 : 0);
+                if (MODE == kBegin) {
+                    I.prev[idx] = -42;
+                } else {
+                    const int8_t old = I.ieq[idx];
+                    I.prev[idx] = old;
+                    if (code != old) atomicOr(&L.chg[s], 1);
+                }
+                I.ieq[idx] = code;
+            }
+        }
+        __syncthreads();
+        if (MODE != kTrialPoint) {
+            for (int s = c0 + tid; s < c1; s += kStageThreads) {
+                const int nV = s < N ? NZ : NX;
+                const double* H = s < N ? v.H : v.Ht;
+                const double pt = I.p[s] + a * I.pStep[s];
+                if (MODE != kTrialValue) I.p[s] = pt;
+                L.vals[s] = stage_value(H, L.z + (s - c0) * NZ, L.q + (s - c0) * NZ, pt, nV);
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == kTrialPoint) return 0.;
+    // objective: stage values summed in horizon order
+    if (tid < kWave) {
+        // vals is slot-ordered: positions 0..N-1 are slots head..N-1, 0..head-1, then slot N
+        double acc = accumulate_in_order(0., L.vals + v.head, N - v.head);
+        acc = accumulate_in_order(acc, L.vals, v.head);
+        acc += L.vals[N];
+        if (tid == 0) L.red[0] = acc;
+    }
+    __syncthreads();
+    const double obj = L.red[0];
+    __syncthreads();
+    return obj;
+}
+
+// Publish actSetHasChanged per horizon position and return the last changed
+// position (-1 if none).
+template <bool ALL>
+NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& L) {
+    int last = -1;
+    for (int k = threadIdx.x; k <= v.N; k += kStageThreads) {
+        const int c = ALL ? 1 : L.chg[stage_slot(v, k)];
+        I.chg[k] = (int8_t)c;
+        if (c) last = k;
+    }
+    return block_max(last, L);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(kStageThreads) void k_qp_begin(BatchView v,
+                                                            const double* __restrict__ meas) {
+    extern __shared__ double lds_raw[];
+    const StageLds L = carve(lds_raw, v.N);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    Inst I = instance(v, b);
+
+    // initial-value embedding: pin the stage-0 state to the measured deviation
+    if (tid == 0) {
+        double x0[NS], m[NS], d[NX];
+        const double* xr = I.xref + (size_t)xref_slot(v, 0) * NS;
+#pragma unroll
+        for (int i = 0; i < NS; i++) { x0[i] = xr[i]; m[i] = meas[(size_t)b * NS + i]; }
+        state_to_delta(d, x0, m);
+        const int s0 = stage_slot(v, 0);
+#pragma unroll
+        for (int i = 0; i < NX; i++) { I.zLow[s0 * NZ + i] = d[i]; I.zUpp[s0 * NZ + i] = d[i]; }
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            const double ur = I.uref[s0 * NU + i];
+            I.zLow[s0 * NZ + NX + i] = v.lb[i] - ur;
+            I.zUpp[s0 * NZ + NX + i] = v.ub[i] - ur;
+        }
+    }
+    __syncthreads();
+
+    const double obj = stage_pass<kBegin>(v, I, 1, L);
+    const int last = publish_changes<true>(v, I, L);
+    if (tid == 0) {
+        I.sc->objInc = obj;
+        I.sc->last = last;
+        I.sc->status = ST_RUNNING;
+        I.sc->numIter = 0;
+        I.sc->regularized = 0;
+        I.sc->lsIter = 0;
+    }
+}
+
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v) {
+    extern __shared__ double lds_raw[];
+    const StageLds L = carve(lds_raw, v.N);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    Inst I = instance(v, b);
+    if (I.sc->status != ST_RUNNING) return;
+    const int N = v.N, n = NX * N, eEnd = NZ * N + NX;
+    const bool regularized = I.sc->regularized != 0;
+    double objInc = I.sc->objInc;
+
+    for (int s = tid; s <= N; s += kStageThreads) L.chg[s] = 0;
+
+    // stage directions for the multiplier step dl (dual_qp.c:309-379):
+    // qStep = C' dl_k - dl_{k-1}, pStep = c . dl_k, dz = -(qStep / H); and the smallest
+    // positive step to an active-set change (stage_qp_solver_clipping.c:110-126)
+    double amin = kInfty;
+    for (int e = tid; e < eEnd; e += kStageThreads) {
+        const int s = e / NZ, j = e - s * NZ, k = slot_position(v, s);
+        double qs;
+        if (s < N) {
+            const double* Cc = I.C + (size_t)s * (NX * NZ) + j;
+            const double* l1 = I.dl + k * NX;
+            qs = 0.;
+#pragma unroll
+            for (int i = 0; i < NX; i++) qs += Cc[i * NZ] * l1[i];
+        } else {
+            qs = 0.0;
+        }
+        if (k > 0 && j < NX) qs -= I.dl[(k - 1) * NX + j];
+        I.qStep[e] = qs;
+        const double d = qs / (s < N ? v.H[j] : v.Ht[j]);
+        const double dzv = -d;
+        I.dz[e] = dzv;
+        const double r0 = dzv / I.y[2 * e];
+        const double r1 = dzv / -I.y[2 * e + 1];
+        const double aa = 1. / ((r0 > r1) ? r0 : r1);
+        if (aa > 0. && aa < amin) amin = aa;
+    }
+    for (int s = tid; s <= N; s += kStageThreads) {
+        double ps = 0.;
+        if (s < N) {
+            const double* l1 = I.dl + slot_position(v, s) * NX;
+#pragma unroll
+            for (int i = 0; i < NX; i++) ps += l1[i] * I.c[s * NX + i];
+        }
+        I.pStep[s] = ps;
+    }
+    const double alphaMinAS = block_min(amin, L);     // also orders the writes above
+
+    double alpha;
+    int lsIter = 0;
+    int st = ST_OK;
+    if (alphaMinAS > 1. - kEqTol && !regularized) {
+        alpha = 1.;
+    } else {
+        // backtracking on the dual objective (dual_qp.c:1294-1334)
+        double alphaMax = 1.;
+        const double minProg = kLsMinRel * fabs(objInc) + kLsMinAbs;
+        const double nd = sqrt(block_ordered_sum(n, L, [&](int r) { return I.dl[r] * I.dl[r]; }));
+        alpha = alphaMax;
+        st = ST_LS_MAXITER;
+        for (; lsIter < kMaxLsIter; ++lsIter) {
+            const double obj = stage_pass<kTrialValue>(v, I, alpha, L);
+            if (obj > objInc + minProg) { st = ST_OK; break; }
+            alpha = alpha * kLsReduction;
+            if (nd * (alpha - 0.) < kEqTol) { alpha = 0.; st = ST_LS_MIN_STEP; break; }
+        }
+        if (st == ST_LS_MIN_STEP) {
+            if (tid == 0) {
+                I.sc->status = ST_NO_ASCENT;
+                I.sc->alpha = alpha;
+                I.sc->lsIter = lsIter;
+            }
+            return;
+        }
+        {
+            const double cand = alpha / kLsReduction;
+            alphaMax = (alphaMax < cand) ? alphaMax : cand;
+        }
+        // gradient bisection (dual_qp.c:1341-1470)
+        auto slope_at = [&](double at) {
+            stage_pass<kTrialPoint>(v, I, at, L);
+            return block_ordered_sum(n, L, [&](int r) {
+                return gradient_row(v, I, I.tmp, r) * I.dl[r];
+            });
+        };
+        double alphaMin = alphaMinAS, alphaC = 1.0, slope;
+        const double normal = (1. < nd) ? 1. : nd;
+        bool done = false;
+        st = ST_LS_MAXITER;
+        for (; lsIter < kMaxLsRefine; ++lsIter) {
+            slope = slope_at(alphaMax);
+            if (fabs(slope / normal) <= kLsStatTol) { alpha = alphaMax; st = ST_OK; done = true; break; }
+            if (slope / normal < 0.) break;
+            alphaMin = alphaMax;
+            alphaMax *= kLsIncrease;
+            if (alphaMax > kLsMaxStep) { alpha = alphaMin; st = ST_LS_MAX_STEP; done = true; break; }
+        }
+        if (!done) {
+            for (; lsIter < kMaxLsRefine; ++lsIter) {
+                alphaC = 0.5 * (alphaMin + alphaMax);
+                slope = slope_at(alphaC);
+                if (fabs(slope / normal) <= kLsStatTol) { alpha = alphaC; st = ST_OK; done = true; break; }
+                if (slope > 0) alphaMin = alphaC; else alphaMax = alphaC;
+            }
+            if (!done) alpha = alphaC;
+        }
+    }
+
+    // commit: multipliers, stage variables, objective, active sets
+    for (int r = tid; r < n; r += kStageThreads) {
+        double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
+        *lp = *lp + alpha * I.dl[r];
+    }
+    objInc = stage_pass<kCommit>(v, I, alpha, L);
+    const int last = publish_changes<false>(v, I, L);
+    if (tid == 0) {
+        I.sc->objInc = objInc;
+        I.sc->alpha = alpha;
+        I.sc->lsIter = lsIter;
+        I.sc->last = last;
+    }
+}
+
+void launch_qp_begin(const BatchView& v, const double* meas, hipStream_t s) {
+    hipLaunchKernelGGL(k_qp_begin, dim3(v.B), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
+}
+void launch_newton_step(const BatchView& v, hipStream_t s) {
+    hipLaunchKernelGGL(k_newton_step, dim3(v.B), dim3(kStageThreads), stage_lds_bytes(v.N), s, v);
+}
+
+}  // namespace nmpc
