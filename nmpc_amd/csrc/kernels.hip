@@ -26,51 +26,6 @@ namespace nmpc {
 
 namespace {
 
-// ------------------------------------------------------------------------
-// Stage-QP re-staging for the clipping solver with a diagonal Hessian and a
-// zero linear term (qpDUNES/setup_qp.c:547-585, stage_qp_solver_clipping.c:42-98):
-// q := 0, qStep := C' lambda_{k+1} - lambda_k (+ g), pStep := c . lambda_{k+1},
-// dz := -(qStep / H), zUnc := 0.  One thread does a whole stage.
-NMPC_DEV void restage_serial(const BatchView& v, const Inst& I, int k) {
-    const int s = stage_slot(v, k), nV = k < v.N ? NZ : NX;
-    const double* H = stage_hessian(v, k);
-    double qs[NZ];
-    double ps = 0.;
-    if (k < v.N) {
-        const double* l1 = I.lam + (size_t)lam_slot(v, k) * NX;
-        const double* Ck = I.C + (size_t)s * (NX * NZ);
-        const double* ck = I.c + (size_t)s * NX;
-#pragma unroll
-        for (int j = 0; j < NZ; j++) qs[j] = 0.;
-        for (int i = 0; i < NX; i++) {
-            const double li = l1[i];
-#pragma unroll
-            for (int j = 0; j < NZ; j++) qs[j] += Ck[i * NZ + j] * li;
-        }
-        for (int i = 0; i < NX; i++) ps += l1[i] * ck[i];
-    } else {
-#pragma unroll
-        for (int j = 0; j < NZ; j++) qs[j] = 0.0;
-    }
-    if (k > 0) {
-        const double* l0 = I.lam + (size_t)lam_slot(v, k - 1) * NX;
-#pragma unroll
-        for (int i = 0; i < NX; i++) qs[i] -= l0[i];
-    }
-    I.pStep[s] = ps;
-#pragma unroll
-    for (int i = 0; i < NZ; i++) {
-        if (i < nV) {
-            double t = qs[i] + 0.0;
-            I.qStep[s * NZ + i] = t;
-            double d = t / H[i];
-            I.dz[s * NZ + i] = -d;
-            I.zUnc[s * NZ + i] = 0.0;
-            I.q[s * NZ + i] = 0.0;
-        }
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------
@@ -93,8 +48,12 @@ __global__ void k_store_refs(BatchView v, const double* __restrict__ refs,
 }
 
 // ------------------------------------------------------------------------
-// nmpc_init: zero Jacobians and residuals, global bounds, re-stage every
-// stage QP against the current multipliers, invalidate the active-set record.
+// nmpc_init: global bounds, every stage QP re-staged against the current
+// multipliers, active-set record invalidated.  The Jacobians C and residuals c
+// are zeroed by the caller with a device memset just before this kernel, so the
+// re-staging (qpDUNES/setup_qp.c:547-585, stage_qp_solver_clipping.c:42-98:
+// q := 0, qStep := C' lambda_{k+1} - lambda_k + g, pStep := c . lambda_{k+1},
+// dz := -(qStep / H), zUnc := 0) multiplies the multipliers by literal zeros.
 // One thread per (instance, stage).
 __global__ void k_init_stages(BatchView v) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,22 +61,48 @@ __global__ void k_init_stages(BatchView v) {
     if (t >= v.B * N1) return;
     const int b = t / N1, k = t % N1;
     Inst I = instance(v, b);
-    const int s = stage_slot(v, k);
+    const int s = stage_slot(v, k), nV = k < v.N ? NZ : NX;
+    const double* H = stage_hessian(v, k);
+    double qs[NZ];
+    double ps = 0.;
     if (k < v.N) {
-        for (int e = 0; e < NX * NZ; e++) I.C[(size_t)s * (NX * NZ) + e] = 0.0;
-        for (int e = 0; e < NX; e++) I.c[s * NX + e] = 0.0;
-    }
-    for (int e = 0; e < NX; e++) {
-        I.zLow[s * NZ + e] = -kInfty;
-        I.zUpp[s * NZ + e] = kInfty;
-    }
-    if (k < v.N)
-        for (int e = 0; e < NU; e++) {
-            I.zLow[s * NZ + NX + e] = v.lb[e];
-            I.zUpp[s * NZ + NX + e] = v.ub[e];
+        const double* l1 = I.lam + (size_t)lam_slot(v, k) * NX;
+#pragma unroll
+        for (int j = 0; j < NZ; j++) qs[j] = 0.;
+        for (int i = 0; i < NX; i++) {
+            const double li = l1[i];
+#pragma unroll
+            for (int j = 0; j < NZ; j++) qs[j] += 0.0 * li;
+            ps += li * 0.0;
         }
-    restage_serial(v, I, k);
-    for (int e = 0; e < NZ; e++) I.prev[k * NZ + e] = -42;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NZ; j++) qs[j] = 0.0;
+    }
+    if (k > 0) {
+        const double* l0 = I.lam + (size_t)lam_slot(v, k - 1) * NX;
+#pragma unroll
+        for (int i = 0; i < NX; i++) qs[i] -= l0[i];
+    }
+    I.pStep[s] = ps;
+#pragma unroll
+    for (int i = 0; i < NZ; i++) {
+        if (i < nV) {
+            const double qv = qs[i] + 0.0;
+            I.qStep[s * NZ + i] = qv;
+            const double d = qv / H[i];
+            I.dz[s * NZ + i] = -d;
+            I.zUnc[s * NZ + i] = 0.0;
+            I.q[s * NZ + i] = 0.0;
+            double lo = -kInfty, up = kInfty;
+            if (i >= NX) { lo = v.lb[i - NX]; up = v.ub[i - NX]; }
+            I.zLow[s * NZ + i] = lo;
+            I.zUpp[s * NZ + i] = up;
+            I.prev[k * NZ + i] = -42;
+        }
+    }
+    if (k == v.N)
+        for (int i = NX; i < NZ; i++) I.prev[k * NZ + i] = -42;
 }
 
 // ------------------------------------------------------------------------
@@ -259,8 +244,8 @@ __global__ __launch_bounds__(256) void k_rk4_free(long n, const double* __restri
 // ------------------------------------------------------------------------
 // One thread per instance.
 __global__ void k_qp_finish(BatchView v) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= v.B) return;
+    const int b = v.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= v.b0 + v.nb) return;
     Inst I = instance(v, b);
     Scalars* sc = I.sc;
     if (sc->status == ST_RUNNING) {
@@ -328,7 +313,7 @@ void launch_rk4_free(long n, const double* x, const double* u, const double* w, 
     hipLaunchKernelGGL(k_rk4_free, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, x, u, w, delta, out);
 }
 void launch_qp_finish(const BatchView& v, hipStream_t s) {
-    hipLaunchKernelGGL(k_qp_finish, dim3(blocks_for(v.B, 256)), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_qp_finish, dim3(blocks_for(v.nb, 256)), dim3(256), 0, s, v);
 }
 void launch_shift_lambda_tail(const BatchView& v, hipStream_t s) {
     hipLaunchKernelGGL(k_shift_lambda_tail, dim3(blocks_for((long)v.B * NX, 256)), dim3(256), 0, s, v);

@@ -51,6 +51,7 @@ struct Scalars {        // one per instance
 
 struct BatchView {
     int B, N;
+    int b0, nb;         // instance range [b0, b0 + nb) the QP kernels of one launch cover
     int head, xhead, lhead;
     double* xref;       // [B][N+1][13]
     double* uref;       // [B][N][3]      stage slot

@@ -1,12 +1,8 @@
-// Newton-system half of the dual Newton solve: one 64-lane wavefront
-// (= one workgroup) per controller instance.
+// Newton-system half of the dual Newton solve: four controller instances per
+// 64-lane wavefront.
 //
-//   k_newton_setup    dual gradient, convergence test, Newton Hessian blocks
-//                     (ccs-c66x/qpDUNES/dual_qp.c:423-597)
 //   k_newton_solve    reverse block-tridiagonal Cholesky, regularisation,
 //                     two substitutions (dual_qp.c:601-698, 817-908, 993-1055)
-//
-// All solver control flow is per instance, hence wave-uniform.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -18,109 +14,6 @@
 #pragma clang fp contract(off)
 
 namespace nmpc {
-
-namespace {
-
-constexpr int kChunk = 512;          // doubles of LDS used by ordered sums
-
-// Sum term(0) + term(1) + ... + term(n-1) in index order, starting from 0.
-// term(r) is evaluated by lane r % 64 (any side effects included); the
-// accumulation is done redundantly by every lane, so the result is uniform.
-template <class F>
-NMPC_DEV double ordered_sum(int n, double* lds, F term) {
-    const int lane = threadIdx.x;
-    double acc = 0.;
-    for (int base = 0; base < n; base += kChunk) {
-        const int len = (n - base < kChunk) ? n - base : kChunk;
-        for (int r = lane; r < len; r += kWave) lds[r] = term(base + r);
-        __syncthreads();
-        for (int t = 0; t < len; t++) acc += lds[t];
-        __syncthreads();
-    }
-    return acc;
-}
-
-}  // namespace
-
-// ------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void k_newton_setup(BatchView v, int it) {
-    __shared__ double lds[kChunk];
-    __shared__ double Cs[NX * NZ];
-    __shared__ double Zs[NZ * NX];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    Inst I = instance(v, b);
-    if (I.sc->status != ST_RUNNING) return;
-    const int N = v.N;
-
-    // gradient and its norm
-    const double nn = ordered_sum(NX * N, lds, [&](int r) {
-        const double g = gradient_row(v, I, I.z, r);
-        I.grad[r] = g;
-        return g * g;
-    });
-    if (lane == 0) { I.sc->numIter = it; I.sc->regularized = 0; }
-    if (sqrt(nn) < kStatTol) {
-        if (lane == 0) I.sc->status = ST_OPTIMAL;
-        return;
-    }
-
-    // Newton Hessian blocks of stages whose active set changed
-    for (int k = 0; k < N; k++) {
-        const bool ck = I.chg[k] != 0, cn = I.chg[k + 1] != 0;
-        if (!(ck || cn)) continue;
-        const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);
-        const double* Hn = stage_hessian(v, k + 1);
-        const double* Cg = I.C + (size_t)s * (NX * NZ);
-        // free columns of stage k; fixed states of stage k+1
-        bool fr = false, fx = false;
-        if (lane < NZ)
-            fr = (I.y[2 * s * NZ + 2 * lane] <= kEqTol) &&
-                 (I.y[2 * s * NZ + 2 * lane + 1] <= kEqTol);
-        if (lane < NX)
-            fx = (I.y[2 * sn * NZ + 2 * lane] >= kEqTol) ||
-                 (I.y[2 * sn * NZ + 2 * lane + 1] >= kEqTol);
-        const unsigned long long freeMask = __ballot(fr);
-        const unsigned long long fixMask = __ballot(fx);
-        for (int e = lane; e < NX * NZ; e += kWave) {
-            Cs[e] = Cg[e];
-            const int l = e / NX, j = e % NX;
-            Zs[e] = Cg[j * NZ + l] / v.H[l];
-        }
-        __syncthreads();
-        // diagonal block: E P_{k+1} E' + C_k P_k C_k'
-        if (lane < 48) {
-            const int i = lane >> 2, j0 = (lane & 3) * 3;
-            double m[3];
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                m[t] = 0.;
-                if (i == j0 + t) {
-                    m[t] = 1. / Hn[i];
-                    if ((fixMask >> i) & 1ull) m[t] = 0.;
-                }
-            }
-            for (int l = 0; l < NZ; l++) {
-                if (!((freeMask >> l) & 1ull)) continue;
-                const double ci = Cs[i * NZ + l];
-#pragma unroll
-                for (int t = 0; t < 3; t++) m[t] += ci * Zs[l * NX + j0 + t];
-            }
-            double* Hd = I.hess + (size_t)k * 2 * NX * NX + i * 2 * NX + NX + j0;
-#pragma unroll
-            for (int t = 0; t < 3; t++) Hd[t] = m[t];
-        }
-        // sub-diagonal block: -C_k[:, :12] P_k
-        if (k >= 1 && ck) {
-            for (int e = lane; e < NX * NX; e += kWave) {
-                const int i = e / NX, j = e % NX;
-                const double val = Cs[i * NZ + j] / v.H[j];
-                I.hess[(size_t)k * 2 * NX * NX + i * 2 * NX + j] =
-                    ((freeMask >> j) & 1ull) ? -val : 0.;
-            }
-        }
-        __syncthreads();
-    }
-}
 
 namespace {
 
@@ -358,10 +251,11 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 // dual_qp.c:601-698 followed by :993-1055
 __global__ __launch_bounds__(kWave) void k_newton_solve(BatchView v) {
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
-    const int bRaw = blockIdx.x * kGroupsPerWave + g;
-    const int b = bRaw < v.B ? bRaw : v.B - 1;
+    const int bEnd = v.b0 + v.nb;
+    const int bRaw = v.b0 + blockIdx.x * kGroupsPerWave + g;
+    const int b = bRaw < bEnd ? bRaw : bEnd - 1;
     Inst I = instance(v, b);
-    bool live = (bRaw < v.B) && (I.sc->status == ST_RUNNING);
+    bool live = (bRaw < bEnd) && (I.sc->status == ST_RUNNING);
     if (!__any(live)) return;
     const int N = v.N;
     const int last = I.sc->last;
@@ -386,11 +280,8 @@ __global__ __launch_bounds__(kWave) void k_newton_solve(BatchView v) {
     forward_pass(v, I, live, t);
 }
 
-void launch_newton_setup(const BatchView& v, int it, hipStream_t s) {
-    hipLaunchKernelGGL(k_newton_setup, dim3(v.B), dim3(kWave), 0, s, v, it);
-}
 void launch_newton_solve(const BatchView& v, hipStream_t s) {
-    const unsigned blocks = (unsigned)((v.B + kGroupsPerWave - 1) / kGroupsPerWave);
+    const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
     hipLaunchKernelGGL(k_newton_solve, dim3(blocks), dim3(kWave), 0, s, v);
 }
 

@@ -2,12 +2,18 @@
 // controller instance.
 //
 //   k_qp_begin     initial-value embedding and the opening step
-//                  (ccs-c66x/cnmpc.c:675-702, qpDUNES/dual_qp.c:56-100)
+//                  (ccs-c66x/cnmpc.c:675-702, qpDUNES/dual_qp.c:56-100),
+//                  then the Newton set-up of iteration 1
 //   k_newton_step  stage directions for the multiplier step, step-length
 //                  selection (full step / backtracking / gradient bisection),
 //                  commit, active-set bookkeeping
 //                  (dual_qp.c:309-379, 1119-1470, 1542-1699;
-//                   stage_qp_solver_clipping.c:42-198)
+//                   stage_qp_solver_clipping.c:42-198),
+//                  then the Newton set-up of the next iteration
+//   Newton set-up = dual gradient, convergence test, Newton Hessian block rows
+//                  (dual_qp.c:423-597).  It is fused behind the kernels above so
+//                  that instances that are done stepping go on while others are
+//                  still in their line search.
 //
 // Element-wise stage work (step, clip, gaps, linear term) runs over the flat
 // slot-ordered index e = 15 slot + i, so global accesses are contiguous across
@@ -220,6 +226,90 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
     return block_max(last, L);
 }
 
+// ------------------------------------------------------------------------
+// Dual gradient and its norm (convergence test), then the Newton Hessian block
+// rows of every stage whose active set changed (dual_qp.c:423-597).  Each of
+// the four wavefronts assembles every fourth block row: it stages C_k and
+// C_k' P_k in its own slice of LDS, 48 lanes then own three entries of the
+// 12x12 diagonal block each and add the free columns' dyads in column order.
+NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it) {
+    const int tid = threadIdx.x, N = v.N;
+    const double nn = block_ordered_sum(NX * N, L, [&](int r) {
+        const double g = gradient_row(v, I, I.z, r);
+        I.grad[r] = g;
+        return g * g;
+    });
+    if (tid == 0) { I.sc->numIter = it; I.sc->regularized = 0; }
+    if (sqrt(nn) < kStatTol) {
+        if (tid == 0) I.sc->status = ST_OPTIMAL;
+        return;
+    }
+
+    const int w = tid >> 6, lane = tid & 63;
+    double* Cs = L.buf + w * (2 * NX * NZ);
+    double* Zs = Cs + NX * NZ;
+    for (int k = w; k < N; k += kStageThreads / kWave) {
+        const bool ck = I.chg[k] != 0, cn = I.chg[k + 1] != 0;
+        if (!(ck || cn)) continue;
+        const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);
+        const double* Hn = stage_hessian(v, k + 1);
+        const double* Cg = I.C + (size_t)s * (NX * NZ);
+        // free columns of stage k; fixed states of stage k+1
+        bool fr = false, fx = false;
+        if (lane < NZ)
+            fr = (I.y[2 * s * NZ + 2 * lane] <= kEqTol) &&
+                 (I.y[2 * s * NZ + 2 * lane + 1] <= kEqTol);
+        if (lane < NX)
+            fx = (I.y[2 * sn * NZ + 2 * lane] >= kEqTol) ||
+                 (I.y[2 * sn * NZ + 2 * lane + 1] >= kEqTol);
+        const unsigned long long freeMask = __ballot(fr);
+        const unsigned long long fixMask = __ballot(fx);
+        for (int e = lane; e < NX * NZ; e += kWave) {
+            Cs[e] = Cg[e];
+            const int l = e / NX, j = e % NX;
+            Zs[e] = Cg[j * NZ + l] / v.H[l];
+        }
+        // this wavefront's LDS writes land before its reads below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // diagonal block: E P_{k+1} E' + C_k P_k C_k'
+        if (lane < 48) {
+            const int i = lane >> 2, j0 = (lane & 3) * 3;
+            double m[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                m[t] = 0.;
+                if (i == j0 + t) {
+                    m[t] = 1. / Hn[i];
+                    if ((fixMask >> i) & 1ull) m[t] = 0.;
+                }
+            }
+            for (int l = 0; l < NZ; l++) {
+                if (!((freeMask >> l) & 1ull)) continue;
+                const double ci = Cs[i * NZ + l];
+#pragma unroll
+                for (int t = 0; t < 3; t++) m[t] += ci * Zs[l * NX + j0 + t];
+            }
+            double* Hd = I.hess + (size_t)k * 2 * NX * NX + i * 2 * NX + NX + j0;
+#pragma unroll
+            for (int t = 0; t < 3; t++) Hd[t] = m[t];
+        }
+        // sub-diagonal block: -C_k[:, :12] P_k
+        if (k >= 1 && ck) {
+            for (int e = lane; e < NX * NX; e += kWave) {
+                const int i = e / NX, j = e % NX;
+                const double val = Cs[i * NZ + j] / v.H[j];
+                I.hess[(size_t)k * 2 * NX * NX + i * 2 * NX + j] =
+                    ((freeMask >> j) & 1ull) ? -val : 0.;
+            }
+        }
+        // reads done before the next block row overwrites the slice
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------
@@ -227,7 +317,7 @@ __global__ __launch_bounds__(kStageThreads) void k_qp_begin(BatchView v,
                                                             const double* __restrict__ meas) {
     extern __shared__ double lds_raw[];
     const StageLds L = carve(lds_raw, v.N);
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
 
     // initial-value embedding: pin the stage-0 state to the measured deviation
@@ -259,13 +349,15 @@ __global__ __launch_bounds__(kStageThreads) void k_qp_begin(BatchView v,
         I.sc->regularized = 0;
         I.sc->lsIter = 0;
     }
+    __syncthreads();
+    newton_setup(v, I, L, 1);
 }
 
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v) {
+__global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int nextIt) {
     extern __shared__ double lds_raw[];
     const StageLds L = carve(lds_raw, v.N);
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
     if (I.sc->status != ST_RUNNING) return;
     const int N = v.N, n = NX * N, eEnd = NZ * N + NX;
@@ -384,13 +476,17 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v) {
         I.sc->lsIter = lsIter;
         I.sc->last = last;
     }
+    if (nextIt <= kMaxIter) {
+        __syncthreads();
+        newton_setup(v, I, L, nextIt);
+    }
 }
 
 void launch_qp_begin(const BatchView& v, const double* meas, hipStream_t s) {
-    hipLaunchKernelGGL(k_qp_begin, dim3(v.B), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
+    hipLaunchKernelGGL(k_qp_begin, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
 }
-void launch_newton_step(const BatchView& v, hipStream_t s) {
-    hipLaunchKernelGGL(k_newton_step, dim3(v.B), dim3(kStageThreads), stage_lds_bytes(v.N), s, v);
+void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
+    hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, next_it);
 }
 
 }  // namespace nmpc
