@@ -172,7 +172,10 @@ def main():
     kern = {}
     algo_bytes = {}
     for name, (ms, n) in ktimes.items():
-        if n == 0 or name not in work:
+        if n == 0:
+            continue
+        if name not in work:
+            kern[name] = dict(total_ms=round(ms, 3), launches=int(n), avg_ms=round(ms / n, 4))
             continue
         nbytes = sum(al["bytes"] * u for al, u in work[name])
         nflop = sum(al["flop"] * u for al, u in work[name])
@@ -180,7 +183,7 @@ def main():
         kern[name] = dict(total_ms=round(ms, 3), launches=int(n), avg_ms=round(ms / n, 4),
                           algo_GBps=round(nbytes / 1e9 / (ms / 1e3), 1),
                           algo_TFLOPs=round(nflop / 1e12 / (ms / 1e3), 3))
-    dominant = max(kern, key=lambda k: kern[k]["total_ms"])
+    dominant = max(algo_bytes, key=lambda k: kern[k]["total_ms"])
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):

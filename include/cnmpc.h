@@ -189,7 +189,7 @@ int nmpc_batch_get_solver_info(nmpc_batch_t *b, uint32_t instance, int32_t info[
 
 /* Per-kernel timing with HIP events on the batch's stream.  kernel ids: */
 enum {
-    NMPC_K_LINEARISE = 0, NMPC_K_QP_BEGIN, NMPC_K_NEWTON_SETUP, NMPC_K_NEWTON_SOLVE,
+    NMPC_K_LINEARISE = 0, NMPC_K_QP_BEGIN, NMPC_K_LINE_SEARCH_TAIL, NMPC_K_NEWTON_SOLVE,
     NMPC_K_NEWTON_STEP, NMPC_K_OTHER, NMPC_K_COUNT
 };
 int nmpc_batch_set_profiling(nmpc_batch_t *b, int enabled);

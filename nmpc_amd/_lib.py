@@ -13,8 +13,8 @@ REAL = C.c_double
 PREAL = C.POINTER(C.c_double)
 PI32 = C.POINTER(C.c_int32)
 
-K_LINEARISE, K_QP_BEGIN, K_NEWTON_SETUP, K_NEWTON_SOLVE, K_NEWTON_STEP, K_OTHER = range(6)
-KERNEL_NAMES = ("linearise", "qp_begin", "newton_setup", "newton_solve",
+K_LINEARISE, K_QP_BEGIN, K_LINE_SEARCH_TAIL, K_NEWTON_SOLVE, K_NEWTON_STEP, K_OTHER = range(6)
+KERNEL_NAMES = ("linearise", "qp_begin", "line_search_tail", "newton_solve",
                 "newton_step", "other")
 
 

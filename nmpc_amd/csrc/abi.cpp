@@ -92,11 +92,10 @@ struct nmpc_batch {
     double wq[12], wr[3], wt[12], lb[3], ub[3];
     bool initialised = false;
     Staging in_refs, in_meas, in_wind, out_u, out_status, out_iters, scratch;
-    // The QP solve of a batch is split into sub-batches on private streams so
-    // that the serial tail of one sub-batch overlaps other sub-batches' work.
-    std::vector<hipStream_t> sub_streams;
-    std::vector<hipEvent_t> sub_done;
-    hipEvent_t fork = nullptr;
+    // nmpc_batch_init leaves the Jacobians C and residuals c logically zero; the
+    // clear itself is postponed until something is about to read or partly
+    // overwrite them, and dropped when every stage is linearised first.
+    bool jacobians_zero_pending = false;
     bool profiling = false;
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
@@ -177,6 +176,16 @@ void sync_config(nmpc_batch* b) {
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Carries out the postponed clear of C and c.
+int materialise_jacobians(nmpc_batch* b) {
+    if (!b->jacobians_zero_pending) return 0;
+    const BatchView& v = b->v;
+    HIP_TRY(hipMemsetAsync(v.C, 0, (size_t)v.B * v.N * 180 * sizeof(double), b->stream));
+    HIP_TRY(hipMemsetAsync(v.c, 0, (size_t)v.B * v.N * 12 * sizeof(double), b->stream));
+    b->jacobians_zero_pending = false;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -223,6 +232,7 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
         {(void**)&v.dl, B * N * 12 * d},    {(void**)&v.grad, B * N * 12 * d},
         {(void**)&v.ieq, B * N1 * 15},      {(void**)&v.prev, B * N1 * 15},
         {(void**)&v.chg, B * N1},           {(void**)&v.sc, B * sizeof(Scalars)},
+        {(void**)&v.tailCount, 8 * sizeof(int)}, {(void**)&v.tailList, B * sizeof(int)},
         {(void**)&v.C, B * N * 180 * d},
         {(void**)&v.hess, B * N * 288 * d}, {(void**)&v.chol, B * N * 288 * d},
     };
@@ -251,30 +261,6 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
         *f.p = (char*)b->arena + off;
         off += align_up(f.bytes);
     }
-    {
-        // Measured on MI355X at 4096 instances: 2 sub-batches +2 %, 4 and 8 slower
-        // (kernels of different streams overlap only partly), so the default is one.
-        int nsub = 1;
-        if (const char* e = getenv("NMPC_SUBBATCHES")) nsub = atoi(e);
-        if (nsub < 1) nsub = 1;
-        if (nsub > 16) nsub = 16;
-        if ((uint32_t)nsub > instances) nsub = (int)instances;
-        if (instances < 256) nsub = 1;              // small batches: one launch sequence
-        if (nsub > 1) {
-            bool ok = hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
-            for (int i = 0; i < nsub && ok; i++) {
-                hipStream_t st; hipEvent_t ev;
-                ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-                if (ok) b->sub_streams.push_back(st);
-                ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-                if (ok) b->sub_done.push_back(ev);
-            }
-            if (!ok) {
-                nmpc_batch_destroy(b);
-                return fail(NMPC_E_HIP, "could not create sub-batch streams");
-            }
-        }
-    }
     memset(b->wq, 0, sizeof b->wq); memset(b->wr, 0, sizeof b->wr);
     memset(b->wt, 0, sizeof b->wt); memset(b->lb, 0, sizeof b->lb);
     memset(b->ub, 0, sizeof b->ub);
@@ -290,9 +276,6 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
     for (auto ev : b->free_events) (void)hipEventDestroy(ev);
     b->in_refs.release(); b->in_meas.release(); b->in_wind.release();
     b->out_u.release(); b->out_status.release(); b->out_iters.release(); b->scratch.release();
-    for (auto st : b->sub_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    for (auto ev : b->sub_done) (void)hipEventDestroy(ev);
-    if (b->fork) (void)hipEventDestroy(b->fork);
     if (b->arena) (void)hipFree(b->arena);
     if (b->own_stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -340,8 +323,7 @@ int nmpc_batch_init(nmpc_batch_t* b) {
     sync_config(b);
     v.head = 0;   // the interval order is rebuilt (ccs-c66x/cnmpc.c:817-828)
     // Jacobians and residuals start at zero (ccs-c66x/cnmpc.c:913-917)
-    HIP_TRY(hipMemsetAsync(v.C, 0, (size_t)v.B * v.N * 180 * sizeof(double), b->stream));
-    HIP_TRY(hipMemsetAsync(v.c, 0, (size_t)v.B * v.N * 12 * sizeof(double), b->stream));
+    b->jacobians_zero_pending = true;
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_init_stages(v, b->stream); }));
     b->initialised = true;
     return 0;
@@ -373,6 +355,10 @@ int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_
     // point i linearises stage i-1
     const int lin_first = first == 0 ? 0 : (int)first - 1;
     const int lin_count = first == 0 ? (int)count - 1 : (int)count;
+    if (lin_first == 0 && lin_count == b->v.N)
+        b->jacobians_zero_pending = false;      // every stage is rewritten below
+    else
+        TRY(materialise_jacobians(b));
     if (lin_count > 0)
         TRY(timed(b, NMPC_K_LINEARISE, [&] {
             launch_linearise(b->v, lin_first, lin_count, b->stream);
@@ -391,35 +377,20 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     if (!b->initialised) return fail(NMPC_E_STATE, "nmpc_batch_feedback_step before nmpc_batch_init");
     TRY(use_device(b));
     sync_config(b);
+    TRY(materialise_jacobians(b));
     const void* dev = nullptr;
     const bool host = !is_device_pointer(measurement);
     TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(double), &dev));
     const double* dmeas = (const double*)dev;
-    auto solve_range = [&](hipStream_t st, int b0, int nb) -> int {
-        BatchView v = b->v;
-        v.b0 = b0; v.nb = nb;
-        TRY(timed_on(b, st, NMPC_K_QP_BEGIN, [&] { launch_qp_begin(v, dmeas, st); }));
-        for (int it = 1; it <= max_newton_iterations(); ++it) {
-            TRY(timed_on(b, st, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, st); }));
-            TRY(timed_on(b, st, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, it + 1, st); }));
-        }
-        TRY(timed_on(b, st, NMPC_K_OTHER, [&] { launch_qp_finish(v, st); }));
-        return 0;
-    };
-    const int nsub = (int)b->sub_streams.size();
-    if (nsub <= 1) {
-        TRY(solve_range(b->stream, 0, b->v.B));
-    } else {
-        HIP_TRY(hipEventRecord(b->fork, b->stream));
-        for (int i = 0; i < nsub; i++) {
-            const int lo = (int)((long)b->v.B * i / nsub), hi = (int)((long)b->v.B * (i + 1) / nsub);
-            hipStream_t st = b->sub_streams[i];
-            HIP_TRY(hipStreamWaitEvent(st, b->fork, 0));
-            TRY(solve_range(st, lo, hi - lo));
-            HIP_TRY(hipEventRecord(b->sub_done[i], st));
-        }
-        for (int i = 0; i < nsub; i++) HIP_TRY(hipStreamWaitEvent(b->stream, b->sub_done[i], 0));
+    const BatchView& v = b->v;
+    TRY(timed(b, NMPC_K_QP_BEGIN, [&] { launch_qp_begin(v, dmeas, b->stream); }));
+    for (int it = 1; it <= max_newton_iterations(); ++it) {
+        TRY(timed(b, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, b->stream); }));
+        TRY(timed(b, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, it + 1, b->stream); }));
+        if (line_search_tail_enabled(v))
+            TRY(timed(b, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, b->stream); }));
     }
+    TRY(timed(b, NMPC_K_OTHER, [&] { launch_qp_finish(v, b->stream); }));
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -453,6 +424,7 @@ int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
     if (!b || !new_reference) return fail(NMPC_E_ARG, "nmpc_batch_update_horizon: null argument");
     TRY(use_device(b));
     sync_config(b);
+    TRY(materialise_jacobians(b));
     BatchView& v = b->v;
     const void* dev = nullptr;
     const bool host = !is_device_pointer(new_reference);
@@ -485,6 +457,7 @@ int nmpc_batch_get_stage(nmpc_batch_t* b, uint32_t instance, uint32_t k, real_t*
     if (instance >= (uint32_t)v.B || k > (uint32_t)v.N)
         return fail(NMPC_E_ARG, "nmpc_batch_get_stage: index out of range");
     TRY(use_device(b));
+    TRY(materialise_jacobians(b));
     const size_t N = v.N, N1 = N + 1, ib = instance;
     const size_t s = k < N ? (size_t)((v.head + k) % v.N) : N;
     const size_t nv = k < N ? 15 : 12;

@@ -50,59 +50,45 @@ __global__ void k_store_refs(BatchView v, const double* __restrict__ refs,
 // ------------------------------------------------------------------------
 // nmpc_init: global bounds, every stage QP re-staged against the current
 // multipliers, active-set record invalidated.  The Jacobians C and residuals c
-// are zeroed by the caller with a device memset just before this kernel, so the
-// re-staging (qpDUNES/setup_qp.c:547-585, stage_qp_solver_clipping.c:42-98:
-// q := 0, qStep := C' lambda_{k+1} - lambda_k + g, pStep := c . lambda_{k+1},
+// are zero at this point (the caller clears them), so the re-staging
+// (qpDUNES/setup_qp.c:547-585, stage_qp_solver_clipping.c:42-98: q := 0,
+// qStep := C' lambda_{k+1} - lambda_k + g, pStep := c . lambda_{k+1},
 // dz := -(qStep / H), zUnc := 0) multiplies the multipliers by literal zeros.
-// One thread per (instance, stage).
+// One thread per (instance, position, variable): contiguous stores.
 __global__ void k_init_stages(BatchView v) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N1 = v.N + 1;
-    if (t >= v.B * N1) return;
-    const int b = t / N1, k = t % N1;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = (v.N + 1) * NZ;
+    if (t >= (long)v.B * per) return;
+    const int b = (int)(t / per), r = (int)(t % per);
+    const int k = r / NZ, i = r - k * NZ;
     Inst I = instance(v, b);
-    const int s = stage_slot(v, k), nV = k < v.N ? NZ : NX;
+    I.prev[r] = -42;
+    const int nV = k < v.N ? NZ : NX;
+    if (i >= nV) return;
+    const int s = stage_slot(v, k);
     const double* H = stage_hessian(v, k);
-    double qs[NZ];
-    double ps = 0.;
+    double qs = 0., ps = 0.;
     if (k < v.N) {
         const double* l1 = I.lam + (size_t)lam_slot(v, k) * NX;
-#pragma unroll
-        for (int j = 0; j < NZ; j++) qs[j] = 0.;
-        for (int i = 0; i < NX; i++) {
-            const double li = l1[i];
-#pragma unroll
-            for (int j = 0; j < NZ; j++) qs[j] += 0.0 * li;
+        for (int m = 0; m < NX; m++) {
+            const double li = l1[m];
+            qs += 0.0 * li;
             ps += li * 0.0;
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NZ; j++) qs[j] = 0.0;
     }
-    if (k > 0) {
-        const double* l0 = I.lam + (size_t)lam_slot(v, k - 1) * NX;
-#pragma unroll
-        for (int i = 0; i < NX; i++) qs[i] -= l0[i];
-    }
-    I.pStep[s] = ps;
-#pragma unroll
-    for (int i = 0; i < NZ; i++) {
-        if (i < nV) {
-            const double qv = qs[i] + 0.0;
-            I.qStep[s * NZ + i] = qv;
-            const double d = qv / H[i];
-            I.dz[s * NZ + i] = -d;
-            I.zUnc[s * NZ + i] = 0.0;
-            I.q[s * NZ + i] = 0.0;
-            double lo = -kInfty, up = kInfty;
-            if (i >= NX) { lo = v.lb[i - NX]; up = v.ub[i - NX]; }
-            I.zLow[s * NZ + i] = lo;
-            I.zUpp[s * NZ + i] = up;
-            I.prev[k * NZ + i] = -42;
-        }
-    }
-    if (k == v.N)
-        for (int i = NX; i < NZ; i++) I.prev[k * NZ + i] = -42;
+    if (k > 0 && i < NX) qs -= I.lam[(size_t)lam_slot(v, k - 1) * NX + i];
+    if (i == 0) I.pStep[s] = ps;
+    const double qv = qs + 0.0;
+    const int e = s * NZ + i;
+    I.qStep[e] = qv;
+    const double d = qv / H[i];
+    I.dz[e] = -d;
+    I.zUnc[e] = 0.0;
+    I.q[e] = 0.0;
+    double lo = -kInfty, up = kInfty;
+    if (i >= NX) { lo = v.lb[i - NX]; up = v.ub[i - NX]; }
+    I.zLow[e] = lo;
+    I.zUpp[e] = up;
 }
 
 // ------------------------------------------------------------------------
@@ -295,8 +281,8 @@ void launch_store_refs(const BatchView& v, const double* refs, int first, int co
     hipLaunchKernelGGL(k_store_refs, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, refs, first, count);
 }
 void launch_init_stages(const BatchView& v, hipStream_t s) {
-    const long n = (long)v.B * (v.N + 1);
-    hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 64)), dim3(64), 0, s, v);
+    const long n = (long)v.B * (v.N + 1) * NZ;
+    hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 256)), dim3(256), 0, s, v);
 }
 void launch_linearise(const BatchView& v, int first, int count, hipStream_t s) {
     const long n = (long)v.B * count * 16;

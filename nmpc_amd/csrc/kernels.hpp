@@ -19,6 +19,8 @@ void launch_rk4_free(long n, const double* x, const double* u, const double* win
 void launch_qp_begin(const BatchView& v, const double* meas, hipStream_t s);
 void launch_newton_solve(const BatchView& v, hipStream_t s);
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s);
+bool line_search_tail_enabled(const BatchView& v);
+void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s);
 void launch_qp_finish(const BatchView& v, hipStream_t s);
 void launch_shift_lambda_tail(const BatchView& v, hipStream_t s);
 void launch_gather_results(const BatchView& v, double* u, int* status, int* iters, hipStream_t s);

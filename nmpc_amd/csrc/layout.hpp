@@ -47,6 +47,10 @@ struct Scalars {        // one per instance
     int regularized;    // Newton Hessian regularised this iteration
     int lsIter;         // line-search trial count of the last iteration
     int lastResult;     // 1 = nmpc_get_controls would return NMPC_OK
+    // step-length search handed from k_newton_step to k_line_search_tail
+    double lsMin, lsMax, lsMid, lsNormal;
+    int lsPhase;
+    int lsDeferred;
 };
 
 struct BatchView {
@@ -78,6 +82,8 @@ struct BatchView {
     int8_t* prev;       // [B][N+1][15]
     int8_t* chg;        // [B][N+1]       actSetHasChanged
     Scalars* sc;        // [B]
+    int* tailCount;     // [8]  instances handed to k_line_search_tail, per Newton iteration
+    int* tailList;      // [B]  their indices
     double H[15];       // regular-stage Hessian diagonal as the solver sees it
     double Ht[12];      // terminal-stage Hessian diagonal
     double lb[3], ub[3];

@@ -138,6 +138,20 @@ NMPC_DEV double stage_value(const double* H, const double* z, const double* q,
 
 // Row r = 12 k + i of the dual gradient: C_k z_k + c_k - z_{k+1}
 // (dual_qp.c:574-597) evaluated on the primal array `zz` (slot-indexed).
+// A row of C is 15 contiguous doubles, 8-byte aligned: fetch it as seven
+// 16-byte loads and one 8-byte load, which halves the number of cache-line
+// look-ups of a wavefront whose lanes each read their own row.
+typedef double pair_u __attribute__((ext_vector_type(2), aligned(8)));
+NMPC_DEV void load_row15(const double* row, double (&out)[NZ]) {
+#pragma unroll
+    for (int j = 0; j + 1 < NZ; j += 2) {
+        const pair_u p = *(const pair_u*)(row + j);
+        out[j] = p.x;
+        out[j + 1] = p.y;
+    }
+    out[NZ - 1] = row[NZ - 1];
+}
+
 NMPC_DEV double gradient_row(const BatchView& v, const Inst& I, const double* zz, int r) {
     const int k = r / NX, i = r % NX;
     const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);

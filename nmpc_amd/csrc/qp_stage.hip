@@ -36,6 +36,10 @@ namespace nmpc {
 namespace {
 
 constexpr int kStageThreads = 256;
+// k_qp_begin waits on memory most of the time: eight resident wavefronts per
+// SIMD (64 registers per lane, no spills) measured 15 % faster than four.
+// k_newton_step needs about 120 registers; capping it lower spills and is slower.
+#define NMPC_BEGIN_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
 constexpr int kStageChunk = 64;                 // stage slots whose z, q sit in LDS at once
 constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920: z + q, reused as sum buffer
 
@@ -65,22 +69,26 @@ inline size_t stage_lds_bytes(int N) {
 }
 
 // acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order.  The
-// LDS reads of the next eight values are issued before the current eight are
-// added, so the loop runs at the latency of the dependent adds.
+// LDS reads of the next AHEAD values are issued before the current ones are
+// added, so the loop runs at the latency of the dependent adds (about 7 ns each
+// on MI355X: an ordered sum of 1200 values costs 8 to 10 microseconds).
+template <int AHEAD = 8>
 NMPC_DEV double accumulate_in_order(double acc, const double* buf, int len) {
     int t = 0;
-    if (len >= 8) {
-        double c0 = buf[0], c1 = buf[1], c2 = buf[2], c3 = buf[3];
-        double c4 = buf[4], c5 = buf[5], c6 = buf[6], c7 = buf[7];
-        for (t = 8; t + 8 <= len; t += 8) {
-            const double n0 = buf[t], n1 = buf[t + 1], n2 = buf[t + 2], n3 = buf[t + 3];
-            const double n4 = buf[t + 4], n5 = buf[t + 5], n6 = buf[t + 6], n7 = buf[t + 7];
-            acc += c0; acc += c1; acc += c2; acc += c3;
-            acc += c4; acc += c5; acc += c6; acc += c7;
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5; c6 = n6; c7 = n7;
+    if (len >= AHEAD) {
+        double c[AHEAD], nx[AHEAD];
+#pragma unroll
+        for (int i = 0; i < AHEAD; i++) c[i] = buf[i];
+        for (t = AHEAD; t + AHEAD <= len; t += AHEAD) {
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++) nx[i] = buf[t + i];
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++) acc += c[i];
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++) c[i] = nx[i];
         }
-        acc += c0; acc += c1; acc += c2; acc += c3;
-        acc += c4; acc += c5; acc += c6; acc += c7;
+#pragma unroll
+        for (int i = 0; i < AHEAD; i++) acc += c[i];
     }
     for (; t < len; t++) acc += buf[t];
     return acc;
@@ -310,15 +318,96 @@ NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L,
     }
 }
 
+
+// ------------------------------------------------------------------------
+// The gradient-bisection step-length search (dual_qp.c:1341-1470) as a state
+// machine: trial_alpha() names the next trial step, advance() consumes its
+// slope.  Phase 0 grows the bracket from its upper end, phase 1 bisects it.
+struct Bisection {
+    double aMin, aMax, aMid;
+    double alpha;       // result, valid when done
+    int it;             // line-search trial counter (shared with the backtracking phase)
+    int phase;
+    bool done;
+};
+
+NMPC_DEV void settle(Bisection& s) {
+    if (s.done) return;
+    if (s.it >= kMaxLsRefine) {         // trial budget spent: keep the last midpoint
+        s.alpha = s.aMid;
+        s.done = true;
+    }
+}
+
+NMPC_DEV double trial_alpha(const Bisection& s) {
+    return s.phase == 0 ? s.aMax : 0.5 * (s.aMin + s.aMax);
+}
+
+NMPC_DEV void advance(Bisection& s, double slope, double normal) {
+    if (s.phase == 0) {
+        if (fabs(slope / normal) <= kLsStatTol) { s.alpha = s.aMax; s.done = true; return; }
+        if (slope / normal < 0.) { s.phase = 1; settle(s); return; }
+        s.aMin = s.aMax;
+        s.aMax *= kLsIncrease;
+        if (s.aMax > kLsMaxStep) { s.alpha = s.aMin; s.done = true; return; }
+        ++s.it;
+        if (s.it >= kMaxLsRefine) s.phase = 1;
+    } else {
+        s.aMid = 0.5 * (s.aMin + s.aMax);
+        if (fabs(slope / normal) <= kLsStatTol) { s.alpha = s.aMid; s.done = true; return; }
+        if (slope > 0) s.aMin = s.aMid; else s.aMax = s.aMid;
+        ++s.it;
+    }
+    settle(s);
+}
+
+// Commit of the chosen step: multipliers, stage variables, objective, active
+// sets; then the Newton set-up of iteration nextIt.
+NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, double alpha,
+                          int lsIter, int nextIt) {
+    const int tid = threadIdx.x, n = NX * v.N;
+    for (int r = tid; r < n; r += kStageThreads) {
+        double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
+        *lp = *lp + alpha * I.dl[r];
+    }
+    const double objInc = stage_pass<kCommit>(v, I, alpha, L);
+    const int last = publish_changes<false>(v, I, L);
+    if (tid == 0) {
+        I.sc->objInc = objInc;
+        I.sc->alpha = alpha;
+        I.sc->lsIter = lsIter;
+        I.sc->last = last;
+    }
+    if (nextIt <= kMaxIter) {
+        __syncthreads();
+        newton_setup(v, I, L, nextIt);
+    }
+}
+
+// Largest horizon whose stage variables fit the per-thread registers of
+// k_line_search_tail (kTailElems values of each vector per thread).
+constexpr int kTailThreads = 1024;
+constexpr int kTailElems = 2;
+constexpr int kTailPoints = 3;      // trial steps evaluated per round: one + both successors
+constexpr int kTailMaxHorizon = 135;
+static_assert(NZ * (kTailMaxHorizon + 1) <= kTailElems * kTailThreads, "stage vectors must fit");
+static_assert(NX / 2 * kTailMaxHorizon <= kTailThreads, "two gradient rows per thread");
+NMPC_DEV bool tail_capable(const BatchView& v) {
+    return v.tailList != nullptr && v.N <= kTailMaxHorizon;
+}
+inline size_t tail_lds_bytes(int N) {
+    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N) * sizeof(double) + 64;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(kStageThreads) void k_qp_begin(BatchView v,
+__global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(BatchView v,
                                                             const double* __restrict__ meas) {
     extern __shared__ double lds_raw[];
     const StageLds L = carve(lds_raw, v.N);
     const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
+    if (blockIdx.x == 0 && tid < 8 && v.tailCount) v.tailCount[tid] = 0;
 
     // initial-value embedding: pin the stage-0 state to the measured deviation
     if (tid == 0) {
@@ -348,6 +437,7 @@ __global__ __launch_bounds__(kStageThreads) void k_qp_begin(BatchView v,
         I.sc->numIter = 0;
         I.sc->regularized = 0;
         I.sc->lsIter = 0;
+        I.sc->lsDeferred = 0;
     }
     __syncthreads();
     newton_setup(v, I, L, 1);
@@ -433,52 +523,169 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
             const double cand = alpha / kLsReduction;
             alphaMax = (alphaMax < cand) ? alphaMax : cand;
         }
-        // gradient bisection (dual_qp.c:1341-1470)
+        // gradient bisection (dual_qp.c:1341-1470).  Nearly every search ends with
+        // its first trial; the few that go on are handed to k_line_search_tail,
+        // which evaluates them faster than this kernel's resources allow.
         auto slope_at = [&](double at) {
             stage_pass<kTrialPoint>(v, I, at, L);
             return block_ordered_sum(n, L, [&](int r) {
                 return gradient_row(v, I, I.tmp, r) * I.dl[r];
             });
         };
-        double alphaMin = alphaMinAS, alphaC = 1.0, slope;
         const double normal = (1. < nd) ? 1. : nd;
-        bool done = false;
-        st = ST_LS_MAXITER;
-        for (; lsIter < kMaxLsRefine; ++lsIter) {
-            slope = slope_at(alphaMax);
-            if (fabs(slope / normal) <= kLsStatTol) { alpha = alphaMax; st = ST_OK; done = true; break; }
-            if (slope / normal < 0.) break;
-            alphaMin = alphaMax;
-            alphaMax *= kLsIncrease;
-            if (alphaMax > kLsMaxStep) { alpha = alphaMin; st = ST_LS_MAX_STEP; done = true; break; }
-        }
-        if (!done) {
-            for (; lsIter < kMaxLsRefine; ++lsIter) {
-                alphaC = 0.5 * (alphaMin + alphaMax);
-                slope = slope_at(alphaC);
-                if (fabs(slope / normal) <= kLsStatTol) { alpha = alphaC; st = ST_OK; done = true; break; }
-                if (slope > 0) alphaMin = alphaC; else alphaMax = alphaC;
+        Bisection bs{alphaMinAS, alphaMax, 1.0, 0., lsIter, 0, false};
+        settle(bs);
+        const bool handOver = tail_capable(v);
+        int trials = 0;
+        while (!bs.done) {
+            if (handOver && trials >= 1) {
+                if (tid == 0) {
+                    Scalars* sc = I.sc;
+                    sc->lsMin = bs.aMin; sc->lsMax = bs.aMax; sc->lsMid = bs.aMid;
+                    sc->lsNormal = normal;
+                    sc->lsIter = bs.it;
+                    sc->lsPhase = bs.phase;
+                    sc->lsDeferred = 1;
+                    const int at = atomicAdd(&v.tailCount[nextIt - 2], 1);
+                    v.tailList[at] = b;
+                }
+                return;
             }
-            if (!done) alpha = alphaC;
+            advance(bs, slope_at(trial_alpha(bs)), normal);
+            ++trials;
+        }
+        alpha = bs.alpha;
+        lsIter = bs.it;
+    }
+    commit_step(v, I, L, alpha, lsIter, nextIt);
+}
+
+// ------------------------------------------------------------------------
+// Continues the step-length searches k_newton_step handed over.  A 1024-thread
+// workgroup owns one such instance at a time: the stage vectors the trial
+// points are made of stay in registers, trial points and slope terms live in
+// LDS only (the reference's scratch copies of them, zVecTmp and y, are
+// rewritten by the commit anyway), and each round evaluates the next trial step
+// together with both of its possible successors, so a round settles two
+// bisection levels for one ordered accumulation.  Leaves the step length and
+// trial count in the instance's scalars for k_line_search_commit.
+__global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, int nextIt) {
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x;
+    const int N = v.N, n = NX * N, eEnd = NZ * N + NX, E = NZ * (N + 1);
+    double* tp = lds_raw;                                   // [points][E] clipped trial points
+    double* terms = lds_raw + kTailPoints * E;              // [points][n] slope terms
+    double* slopes = terms + kTailPoints * n;               // [points]
+    // gradient rows: thread t < 6 N owns rows h and h + 6 of block t / 6
+    const int rk = tid / (NX / 2), rh = tid % (NX / 2);
+    const bool rowOn = rk < N;
+    const int count = v.tailCount[nextIt - 2];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const int b = v.tailList[item];
+        Inst I = instance(v, b);
+        Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
+        const double normal = I.sc->lsNormal;
+
+        double zu[kTailElems], dzv[kTailElems], lo[kTailElems], up[kTailElems];
+#pragma unroll
+        for (int m = 0; m < kTailElems; m++) {
+            const int e = tid + m * kTailThreads;
+            const bool in = e < eEnd;
+            zu[m] = in ? I.zUnc[e] : 0.;
+            dzv[m] = in ? I.dz[e] : 0.;
+            lo[m] = in ? I.zLow[e] : 0.;
+            up[m] = in ? I.zUpp[e] : 0.;
+        }
+        // this thread's two Jacobian rows, residuals and multiplier-step entries
+        double ca[NZ], cb[NZ], resA = 0., resB = 0., dlA = 0., dlB = 0.;
+#pragma unroll
+        for (int j = 0; j < NZ; j++) { ca[j] = 0.; cb[j] = 0.; }
+        if (rowOn) {
+            const int s = stage_slot(v, rk);
+            const double* blk = I.C + (size_t)s * (NX * NZ);
+            load_row15(blk + rh * NZ, ca);
+            load_row15(blk + (rh + NX / 2) * NZ, cb);
+            resA = I.c[s * NX + rh];
+            resB = I.c[s * NX + rh + NX / 2];
+            dlA = I.dl[rk * NX + rh];
+            dlB = I.dl[rk * NX + rh + NX / 2];
+        }
+        settle(bs);
+        while (!bs.done) {
+            // this round's trial steps: the next one and its successor on either outcome
+            double at[kTailPoints];
+            Bisection neg = bs, pos = bs;
+            at[0] = trial_alpha(bs);
+            advance(neg, -1e300, normal);
+            advance(pos, 1e300, normal);
+            at[1] = neg.done ? at[0] : trial_alpha(neg);
+            at[2] = pos.done ? at[0] : trial_alpha(pos);
+#pragma unroll
+            for (int m = 0; m < kTailElems; m++) {
+                const int e = tid + m * kTailThreads;
+                if (e < eEnd) {
+#pragma unroll
+                    for (int p = 0; p < kTailPoints; p++) {
+                        double y0, y1;
+                        tp[p * E + e] = clip_gap(zu[m] + at[p] * dzv[m], lo[m], up[m], &y0, &y1);
+                    }
+                }
+            }
+            __syncthreads();
+            if (rowOn) {
+                const int s = stage_slot(v, rk), sn = stage_slot(v, rk + 1);
+#pragma unroll 1
+                for (int p = 0; p < kTailPoints; p++) {
+                    const double* zk = tp + p * E + s * NZ;
+                    double a = 0., b2 = 0.;
+#pragma unroll
+                    for (int j = 0; j < NZ; j++) {
+                        const double zj = zk[j];
+                        a += ca[j] * zj;
+                        b2 += cb[j] * zj;
+                    }
+                    a += resA;
+                    b2 += resB;
+                    a -= tp[p * E + sn * NZ + rh];
+                    b2 -= tp[p * E + sn * NZ + rh + NX / 2];
+                    terms[p * n + rk * NX + rh] = a * dlA;
+                    terms[p * n + rk * NX + rh + NX / 2] = b2 * dlB;
+                }
+            }
+            __syncthreads();
+            if (tid < kTailPoints) slopes[tid] = accumulate_in_order<16>(0., terms + tid * n, n);
+            __syncthreads();
+            const double s0 = slopes[0], sNeg = slopes[1], sPos = slopes[2];
+            __syncthreads();
+            const int phase0 = bs.phase;
+            advance(bs, s0, normal);
+            if (!bs.done) {
+                const bool tookNeg = phase0 == 0 ? (s0 / normal < 0.) : !(s0 > 0);
+                advance(bs, tookNeg ? sNeg : sPos, normal);
+            }
+        }
+        if (tid == 0) {
+            I.sc->alpha = bs.alpha;
+            I.sc->lsIter = bs.it;
         }
     }
+}
 
-    // commit: multipliers, stage variables, objective, active sets
-    for (int r = tid; r < n; r += kStageThreads) {
-        double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
-        *lp = *lp + alpha * I.dl[r];
-    }
-    objInc = stage_pass<kCommit>(v, I, alpha, L);
-    const int last = publish_changes<false>(v, I, L);
-    if (tid == 0) {
-        I.sc->objInc = objInc;
-        I.sc->alpha = alpha;
-        I.sc->lsIter = lsIter;
-        I.sc->last = last;
-    }
-    if (nextIt <= kMaxIter) {
+// Commit and next Newton set-up of the instances k_line_search_tail finished.
+__global__ __launch_bounds__(kStageThreads) void k_line_search_commit(BatchView v, int nextIt) {
+    extern __shared__ double lds_raw[];
+    const StageLds L = carve(lds_raw, v.N);
+    const int tid = threadIdx.x;
+    const int count = v.tailCount[nextIt - 2];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        Inst I = instance(v, v.tailList[item]);
+        const double alpha = I.sc->alpha;
+        const int lsIter = I.sc->lsIter;
+        for (int s = tid; s <= v.N; s += kStageThreads) L.chg[s] = 0;
         __syncthreads();
-        newton_setup(v, I, L, nextIt);
+        if (tid == 0) I.sc->lsDeferred = 0;
+        commit_step(v, I, L, alpha, lsIter, nextIt);
+        __syncthreads();
     }
 }
 
@@ -487,6 +694,19 @@ void launch_qp_begin(const BatchView& v, const double* meas, hipStream_t s) {
 }
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
     hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, next_it);
+}
+bool line_search_tail_enabled(const BatchView& v) {
+    return v.tailList != nullptr && v.N <= kTailMaxHorizon;
+}
+void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
+    const int grid = v.nb < 256 ? v.nb : 256;
+    const size_t lds = tail_lds_bytes(v.N);
+    if (lds > 64 * 1024)    // beyond the default cap on dynamic LDS
+        (void)hipFuncSetAttribute((const void*)k_line_search_tail,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_line_search_tail, dim3(grid), dim3(kTailThreads), lds, s, v, next_it);
+    hipLaunchKernelGGL(k_line_search_commit, dim3(grid), dim3(kStageThreads), stage_lds_bytes(v.N), s,
+                       v, next_it);
 }
 
 }  // namespace nmpc

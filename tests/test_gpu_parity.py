@@ -262,6 +262,53 @@ def test_device_resident_inputs_match_host_inputs():
     bt.close()
 
 
+def test_piecewise_reference_loading_and_reset():
+    """Reference points loaded in several calls, one by one, or all at once
+    leave identical solver state; stage records right after init hold zero
+    Jacobians; reset + init reproduces the cold solve."""
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B = 20, 9
+    d = S.make_batch(B, N, seed=33, turn_start=(0.05, 0.3))
+    refs, meas = d["refs"][:, :N + 1], d["meas"][:, 0]
+
+    def run(loader, bt=None):
+        bt = bt or Batch(B, N)
+        bt.setup(**S.setup_args())
+        bt.initialise_horizon()
+        bt.set_wind_velocity(d["wind"])
+        loader(bt)
+        bt.solve(meas)
+        out = bt.get_controls()
+        return bt, out, bt.stages(4), bt.globals_(4)
+
+    bt0, o0, s0, g0 = run(lambda bt: bt.set_reference(refs))
+    for loader in (
+        lambda bt: [bt.set_reference(refs[:, a:b], first=a) for a, b in ((0, 8), (8, 9), (9, N + 1))],
+        lambda bt: [bt.set_reference(refs[:, i:i + 1], first=i) for i in range(N + 1)],
+    ):
+        bt1, o1, s1, g1 = run(loader)
+        for a, b, what in zip(o0, o1, ("controls", "status", "iterations")):
+            assert_same(b, a, what)
+        assert_same(s1, s0, "stage records")
+        assert_same(g1, g0, "solver state")
+        bt1.close()
+    # a fresh init leaves zero Jacobians whatever was there before
+    bt0.initialise_horizon()
+    st = bt0.stages(2)
+    assert not st[:, :192].any()
+    bt0.set_reference(refs[:, :5])
+    st = bt0.stages(2)
+    assert st[:4, :192].any(axis=1).all() and not st[4:, :192].any()
+    # reset returns to the state after create
+    bt0.reset()
+    _, o2, s2, g2 = run(lambda bt: bt.set_reference(refs), bt0)
+    for a, b, what in zip(o0, o2, ("controls", "status", "iterations")):
+        assert_same(b, a, what + " after reset")
+    assert_same(s2, s0, "stage records after reset")
+    bt0.close()
+
+
 def test_error_reporting():
     from nmpc_amd import _lib
     from nmpc_amd import synthetic as S

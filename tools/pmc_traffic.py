@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/prof_run.py
+into profiles/traffic.json: mean HBM bytes per launch of every nmpc kernel.
+
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write ...csv> B N
+
+FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte
+read requests as 64 bytes, so the read side is doubled.  The fill launches of
+the same run (hipMemsetAsync of a known byte count) calibrate the write side:
+their measured / requested ratio is stored next to the numbers.
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+SHORT = {"k_linearise": "linearise", "k_qp_begin": "qp_begin", "k_newton_solve": "newton_solve",
+         "k_newton_step": "newton_step", "k_init_stages": "init_stages"}
+
+
+def collect(path, counter):
+    per = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            m = re.search(r"nmpc::(\w+)\(", row["Kernel_Name"])
+            name = m.group(1) if m else row["Kernel_Name"].split("(")[0]
+            per[name].append(float(row["Counter_Value"]))
+    return per
+
+
+def main():
+    fetch_csv, write_csv, B, N = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    fetch = collect(fetch_csv, "FETCH_SIZE")
+    write = collect(write_csv, "WRITE_SIZE")
+    out = {"instances": B, "horizon": N,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over "
+                     "tools/prof_run.py; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+           "bytes_per_launch": {}, "read_bytes_per_launch": {}, "write_bytes_per_launch": {},
+           "launches": {}}
+    for name in sorted(set(fetch) | set(write)):
+        if name not in SHORT:
+            continue
+        r = 2.0 * 1024.0 * sum(fetch.get(name, [0])) / max(1, len(fetch.get(name, [])))
+        w = 1024.0 * sum(write.get(name, [0])) / max(1, len(write.get(name, [])))
+        k = SHORT[name]
+        out["bytes_per_launch"][k] = round(r + w)
+        out["read_bytes_per_launch"][k] = round(r)
+        out["write_bytes_per_launch"][k] = round(w)
+        out["launches"][k] = len(fetch.get(name, []))
+    fills = write.get("__amd_rocclr_fillBufferAligned", [])
+    if fills:
+        out["fill_write_bytes_largest"] = round(1024.0 * max(fills))
+        out["fill_expected_bytes_largest"] = B * N * 180 * 8   # the Jacobian memset of nmpc_batch_init
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       "profiles", "traffic.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
