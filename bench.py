@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--instances", type=int, default=4096, help="controller instances per GPU")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--seed", type=int, default=S.DEFAULT_SEED)
+    ap.add_argument("--warm-steps", type=int, default=20,
+                    help="warm control steps timed after the cold solves (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096,
                     help="instances of the workload the CPU baseline solves")
@@ -153,6 +155,33 @@ def main():
 
     total_instances = B * world
     value = total_instances * a.steps / elapsed
+
+    # ---- warm control steps (reported beside the headline, outside its timed region) ----
+    # The batch holds the last cold solve; every further step is the reference's
+    # control loop: prepare, feedback on a new measurement, get controls, shift the
+    # horizon by one reference point (which linearises one stage).
+    warm = None
+    if rank == 0 and a.warm_steps > 0:
+        dw = S.make_batch(B, N, extra_steps=a.warm_steps, seed=a.seed + rank)
+        wrefs = torch.from_numpy(np.ascontiguousarray(dw["refs"][:, N + 1:])).to(dev)
+        wmeas = torch.from_numpy(np.ascontiguousarray(dw["meas"][:, 1:])).to(dev)
+        wm = [torch.cuda.Event(enable_timing=True) for _ in range(a.warm_steps + 1)]
+        bt.update_horizon(wrefs[:, 0].contiguous())
+        torch.cuda.synchronize(dev)
+        wm[0].record(stream)
+        for k in range(a.warm_steps):
+            bt.prepare()
+            bt.solve(wmeas[:, k].contiguous())
+            bt.get_controls_into(out_u, out_st, out_it)
+            if k + 1 < a.warm_steps:
+                bt.update_horizon(wrefs[:, k + 1].contiguous())
+            wm[k + 1].record(stream)
+        torch.cuda.synchronize(dev)
+        wms = sorted(wm[k].elapsed_time(wm[k + 1]) for k in range(a.warm_steps))
+        warm = dict(steps=a.warm_steps, p50_ms=round(wms[len(wms) // 2], 4),
+                    p99_ms=round(wms[min(len(wms) - 1, int(0.99 * len(wms)))], 4),
+                    steps_per_s=round(B * a.warm_steps / (sum(wms) / 1e3), 1),
+                    ok_frac=round(float((out_st.cpu().numpy() == 0).mean()), 4))
 
     # ---- roofline of the dominant kernel (rank 0's GPU) ----------------------
     # units each launch kind processed over the timed steps
@@ -239,6 +268,7 @@ def main():
                        "parallelism": "instance partition, %d GPU(s)" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "warm_step": warm,
             "kernels": kern,
             "solver": {"converged_frac": round(float((st_all == 0).mean()), 4),
                        "mean_qp_iterations": round(float(it_all.mean()), 3)},

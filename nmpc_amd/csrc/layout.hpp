@@ -48,6 +48,7 @@ struct Scalars {        // one per instance
     int lsIter;         // line-search trial count of the last iteration
     int lastResult;     // 1 = nmpc_get_controls would return NMPC_OK
     // step-length search handed from k_newton_step to k_line_search_tail
+    double dlNorm2;     // squared norm of the Newton step, written by k_newton_solve
     double lsMin, lsMax, lsMid, lsNormal;
     int lsPhase;
     int lsDeferred;

@@ -361,16 +361,47 @@ NMPC_DEV void advance(Bisection& s, double slope, double normal) {
     settle(s);
 }
 
+// Commit of a step whose clipped point and gaps are already in z and y (the last
+// value trial ran at the same step length and nothing has touched them since):
+// what is left is the unclipped point, the linear term, the offsets and the
+// active-set record.  Every value is produced by the expression the full pass
+// uses, so the state is the one stage_pass<kCommit> would leave.
+NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, double a, const StageLds& L) {
+    const int tid = threadIdx.x, N = v.N;
+    const int eEnd = NZ * N + NX;
+    for (int e = tid; e < eEnd; e += kStageThreads) {
+        I.zUnc[e] = I.zUnc[e] + a * I.dz[e];
+        I.q[e] = I.q[e] + a * I.qStep[e];
+        const double y0 = I.y[2 * e], y1 = I.y[2 * e + 1];
+        const int s = e / NZ, i = e - s * NZ;
+        const int idx = slot_position(v, s) * NZ + i;
+        const int8_t code = (y0 > kEqTol) ? -1 : ((y1 > kEqTol) ? 1 : 0);
+        const int8_t old = I.ieq[idx];
+        I.prev[idx] = old;
+        if (code != old) atomicOr(&L.chg[s], 1);
+        I.ieq[idx] = code;
+    }
+    for (int s = tid; s <= N; s += kStageThreads) I.p[s] = I.p[s] + a * I.pStep[s];
+    __syncthreads();
+}
+
 // Commit of the chosen step: multipliers, stage variables, objective, active
-// sets; then the Newton set-up of iteration nextIt.
+// sets; then the Newton set-up of iteration nextIt.  keptObjective points to the
+// objective of the value trial that z and y still hold, or is null.
 NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, double alpha,
-                          int lsIter, int nextIt) {
+                          int lsIter, int nextIt, const double* keptObjective = nullptr) {
     const int tid = threadIdx.x, n = NX * v.N;
     for (int r = tid; r < n; r += kStageThreads) {
         double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
         *lp = *lp + alpha * I.dl[r];
     }
-    const double objInc = stage_pass<kCommit>(v, I, alpha, L);
+    double objInc;
+    if (keptObjective) {
+        commit_kept_trial(v, I, alpha, L);
+        objInc = *keptObjective;
+    } else {
+        objInc = stage_pass<kCommit>(v, I, alpha, L);
+    }
     const int last = publish_changes<false>(v, I, L);
     if (tid == 0) {
         I.sc->objInc = objInc;
@@ -382,6 +413,82 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
         __syncthreads();
         newton_setup(v, I, L, nextIt);
     }
+}
+
+// Stage directions for the multiplier step dl (dual_qp.c:309-379): qStep =
+// C' dl_k - dl_{k-1}, pStep = c . dl_k, dz = -(qStep / H); the smallest positive
+// step to an active-set change (stage_qp_solver_clipping.c:110-126), taken from
+// the gaps of the current point; and, in the same sweep, the value trial at the
+// full step (dual_qp.c:1574-1617), which every branch of the step-length
+// selection starts with or ends at.  Returns the trial objective, *amin the
+// smallest step.
+NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I, const StageLds& L,
+                                               double* aminOut) {
+    const int tid = threadIdx.x, N = v.N;
+    const int eEnd = NZ * N + NX;
+    const double a = 1.;
+    double amin = kInfty;
+    for (int c0 = 0; c0 <= N; c0 += kStageChunk) {
+        const int c1 = (c0 + kStageChunk <= N + 1) ? c0 + kStageChunk : N + 1;
+        const int e0 = c0 * NZ;
+        const int e1 = (c1 * NZ < eEnd) ? c1 * NZ : eEnd;
+        for (int e = e0 + tid; e < e1; e += kStageThreads) {
+            const int s = e / NZ, j = e - s * NZ, k = slot_position(v, s);
+            double qs;
+            if (s < N) {
+                const double* Cc = I.C + (size_t)s * (NX * NZ) + j;
+                const double* l1 = I.dl + k * NX;
+                qs = 0.;
+#pragma unroll
+                for (int i = 0; i < NX; i++) qs += Cc[i * NZ] * l1[i];
+            } else {
+                qs = 0.0;
+            }
+            if (k > 0 && j < NX) qs -= I.dl[(k - 1) * NX + j];
+            I.qStep[e] = qs;
+            const double d = qs / (s < N ? v.H[j] : v.Ht[j]);
+            const double dzv = -d;
+            I.dz[e] = dzv;
+            const double r0 = dzv / I.y[2 * e];
+            const double r1 = dzv / -I.y[2 * e + 1];
+            const double aa = 1. / ((r0 > r1) ? r0 : r1);
+            if (aa > 0. && aa < amin) amin = aa;
+            // value trial at the full step
+            const double zu = I.zUnc[e] + a * dzv;
+            double y0, y1;
+            const double zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
+            I.y[2 * e] = y0;
+            I.y[2 * e + 1] = y1;
+            I.z[e] = zc;
+            L.z[e - e0] = zc;
+            L.q[e - e0] = I.q[e] + a * qs;
+        }
+        __syncthreads();
+        for (int s = c0 + tid; s < c1; s += kStageThreads) {
+            double ps = 0.;
+            if (s < N) {
+                const double* l1 = I.dl + slot_position(v, s) * NX;
+#pragma unroll
+                for (int i = 0; i < NX; i++) ps += l1[i] * I.c[s * NX + i];
+            }
+            I.pStep[s] = ps;
+            const int nV = s < N ? NZ : NX;
+            const double* H = s < N ? v.H : v.Ht;
+            const double pt = I.p[s] + a * ps;
+            L.vals[s] = stage_value(H, L.z + (s - c0) * NZ, L.q + (s - c0) * NZ, pt, nV);
+        }
+        __syncthreads();
+    }
+    if (tid < kWave) {
+        double acc = accumulate_in_order(0., L.vals + v.head, N - v.head);
+        acc = accumulate_in_order(acc, L.vals, v.head);
+        acc += L.vals[N];
+        if (tid == 0) L.red[0] = acc;
+    }
+    __syncthreads();
+    const double obj = L.red[0];
+    *aminOut = block_min(amin, L);
+    return obj;
 }
 
 // Largest horizon whose stage variables fit the per-thread registers of
@@ -456,58 +563,28 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 
     for (int s = tid; s <= N; s += kStageThreads) L.chg[s] = 0;
 
-    // stage directions for the multiplier step dl (dual_qp.c:309-379):
-    // qStep = C' dl_k - dl_{k-1}, pStep = c . dl_k, dz = -(qStep / H); and the smallest
-    // positive step to an active-set change (stage_qp_solver_clipping.c:110-126)
-    double amin = kInfty;
-    for (int e = tid; e < eEnd; e += kStageThreads) {
-        const int s = e / NZ, j = e - s * NZ, k = slot_position(v, s);
-        double qs;
-        if (s < N) {
-            const double* Cc = I.C + (size_t)s * (NX * NZ) + j;
-            const double* l1 = I.dl + k * NX;
-            qs = 0.;
-#pragma unroll
-            for (int i = 0; i < NX; i++) qs += Cc[i * NZ] * l1[i];
-        } else {
-            qs = 0.0;
-        }
-        if (k > 0 && j < NX) qs -= I.dl[(k - 1) * NX + j];
-        I.qStep[e] = qs;
-        const double d = qs / (s < N ? v.H[j] : v.Ht[j]);
-        const double dzv = -d;
-        I.dz[e] = dzv;
-        const double r0 = dzv / I.y[2 * e];
-        const double r1 = dzv / -I.y[2 * e + 1];
-        const double aa = 1. / ((r0 > r1) ? r0 : r1);
-        if (aa > 0. && aa < amin) amin = aa;
-    }
-    for (int s = tid; s <= N; s += kStageThreads) {
-        double ps = 0.;
-        if (s < N) {
-            const double* l1 = I.dl + slot_position(v, s) * NX;
-#pragma unroll
-            for (int i = 0; i < NX; i++) ps += l1[i] * I.c[s * NX + i];
-        }
-        I.pStep[s] = ps;
-    }
-    const double alphaMinAS = block_min(amin, L);     // also orders the writes above
+    double alphaMinAS;
+    // z and y hold the value trial at step length zAlpha, whose objective is objKept
+    double objKept = directions_and_full_step_trial(v, I, L, &alphaMinAS);
+    double zAlpha = 1.;
 
     double alpha;
     int lsIter = 0;
-    int st = ST_OK;
     if (alphaMinAS > 1. - kEqTol && !regularized) {
         alpha = 1.;
     } else {
         // backtracking on the dual objective (dual_qp.c:1294-1334)
         double alphaMax = 1.;
         const double minProg = kLsMinRel * fabs(objInc) + kLsMinAbs;
-        const double nd = sqrt(block_ordered_sum(n, L, [&](int r) { return I.dl[r] * I.dl[r]; }));
+        const double nd = sqrt(I.sc->dlNorm2);
         alpha = alphaMax;
-        st = ST_LS_MAXITER;
+        int st = ST_LS_MAXITER;
         for (; lsIter < kMaxLsIter; ++lsIter) {
-            const double obj = stage_pass<kTrialValue>(v, I, alpha, L);
-            if (obj > objInc + minProg) { st = ST_OK; break; }
+            if (!(alpha == zAlpha)) {
+                objKept = stage_pass<kTrialValue>(v, I, alpha, L);
+                zAlpha = alpha;
+            }
+            if (objKept > objInc + minProg) { st = ST_OK; break; }
             alpha = alpha * kLsReduction;
             if (nd * (alpha - 0.) < kEqTol) { alpha = 0.; st = ST_LS_MIN_STEP; break; }
         }
@@ -525,11 +602,17 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
         }
         // gradient bisection (dual_qp.c:1341-1470).  Nearly every search ends with
         // its first trial; the few that go on are handed to k_line_search_tail,
-        // which evaluates them faster than this kernel's resources allow.
+        // which evaluates them faster than this kernel's resources allow.  A trial
+        // at the step length z already holds needs no new trial point.
         auto slope_at = [&](double at) {
-            stage_pass<kTrialPoint>(v, I, at, L);
+            const double* zz = I.z;
+            if (!(at == zAlpha)) {
+                stage_pass<kTrialPoint>(v, I, at, L);
+                zAlpha = __builtin_nan("");         // y no longer belongs to z
+                zz = I.tmp;
+            }
             return block_ordered_sum(n, L, [&](int r) {
-                return gradient_row(v, I, I.tmp, r) * I.dl[r];
+                return gradient_row(v, I, zz, r) * I.dl[r];
             });
         };
         const double normal = (1. < nd) ? 1. : nd;
@@ -557,7 +640,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
         alpha = bs.alpha;
         lsIter = bs.it;
     }
-    commit_step(v, I, L, alpha, lsIter, nextIt);
+    commit_step(v, I, L, alpha, lsIter, nextIt, (alpha == zAlpha) ? &objKept : nullptr);
 }
 
 // ------------------------------------------------------------------------
