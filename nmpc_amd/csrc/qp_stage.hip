@@ -240,13 +240,24 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
 // the four wavefronts assembles every fourth block row: it stages C_k and
 // C_k' P_k in its own slice of LDS, 48 lanes then own three entries of the
 // 12x12 diagonal block each and add the free columns' dyads in column order.
-NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it) {
+// gradKept: grad already holds the gradient at z (a slope trial at the committed
+// step stored it).
+NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it,
+                           bool gradKept = false) {
     const int tid = threadIdx.x, N = v.N;
-    const double nn = block_ordered_sum(NX * N, L, [&](int r) {
-        const double g = gradient_row(v, I, I.z, r);
-        I.grad[r] = g;
-        return g * g;
-    });
+    double nn;
+    if (gradKept) {
+        nn = block_ordered_sum(NX * N, L, [&](int r) {
+            const double g = I.grad[r];
+            return g * g;
+        });
+    } else {
+        nn = block_ordered_sum(NX * N, L, [&](int r) {
+            const double g = gradient_row(v, I, I.z, r);
+            I.grad[r] = g;
+            return g * g;
+        });
+    }
     if (tid == 0) { I.sc->numIter = it; I.sc->regularized = 0; }
     if (sqrt(nn) < kStatTol) {
         if (tid == 0) I.sc->status = ST_OPTIMAL;
@@ -389,7 +400,8 @@ NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, double a, con
 // sets; then the Newton set-up of iteration nextIt.  keptObjective points to the
 // objective of the value trial that z and y still hold, or is null.
 NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, double alpha,
-                          int lsIter, int nextIt, const double* keptObjective = nullptr) {
+                          int lsIter, int nextIt, const double* keptObjective = nullptr,
+                          bool gradKept = false) {
     const int tid = threadIdx.x, n = NX * v.N;
     for (int r = tid; r < n; r += kStageThreads) {
         double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
@@ -411,7 +423,7 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
     }
     if (nextIt <= kMaxIter) {
         __syncthreads();
-        newton_setup(v, I, L, nextIt);
+        newton_setup(v, I, L, nextIt, gradKept && keptObjective);
     }
 }
 
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
     const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
     if (I.sc->status != ST_RUNNING) return;
-    const int N = v.N, n = NX * N, eEnd = NZ * N + NX;
+    const int N = v.N, n = NX * N;
     const bool regularized = I.sc->regularized != 0;
     double objInc = I.sc->objInc;
 
@@ -567,6 +579,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
     // z and y hold the value trial at step length zAlpha, whose objective is objKept
     double objKept = directions_and_full_step_trial(v, I, L, &alphaMinAS);
     double zAlpha = 1.;
+    double gradAlpha = __builtin_nan("");   // step length whose gradient grad holds, if any
 
     double alpha;
     int lsIter = 0;
@@ -605,14 +618,22 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
         // which evaluates them faster than this kernel's resources allow.  A trial
         // at the step length z already holds needs no new trial point.
         auto slope_at = [&](double at) {
-            const double* zz = I.z;
-            if (!(at == zAlpha)) {
-                stage_pass<kTrialPoint>(v, I, at, L);
-                zAlpha = __builtin_nan("");         // y no longer belongs to z
-                zz = I.tmp;
+            if (at == zAlpha) {
+                // the gradient at z is what the next Newton set-up starts from if this
+                // step length is committed: keep it (the last iteration has no set-up
+                // and leaves the gradient record alone)
+                const bool keep = nextIt <= kMaxIter;
+                if (keep) gradAlpha = at;
+                return block_ordered_sum(n, L, [&](int r) {
+                    const double g = gradient_row(v, I, I.z, r);
+                    if (keep) I.grad[r] = g;
+                    return g * I.dl[r];
+                });
             }
+            stage_pass<kTrialPoint>(v, I, at, L);
+            zAlpha = __builtin_nan("");             // y no longer belongs to z
             return block_ordered_sum(n, L, [&](int r) {
-                return gradient_row(v, I, zz, r) * I.dl[r];
+                return gradient_row(v, I, I.tmp, r) * I.dl[r];
             });
         };
         const double normal = (1. < nd) ? 1. : nd;
@@ -640,7 +661,8 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
         alpha = bs.alpha;
         lsIter = bs.it;
     }
-    commit_step(v, I, L, alpha, lsIter, nextIt, (alpha == zAlpha) ? &objKept : nullptr);
+    commit_step(v, I, L, alpha, lsIter, nextIt, (alpha == zAlpha) ? &objKept : nullptr,
+                alpha == gradAlpha);
 }
 
 // ------------------------------------------------------------------------
