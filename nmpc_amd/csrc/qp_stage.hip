@@ -242,8 +242,9 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
 // 12x12 diagonal block each and add the free columns' dyads in column order.
 // gradKept: grad already holds the gradient at z (a slope trial at the committed
 // step stored it).
-NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it,
-                           bool gradKept = false) {
+// Returns false when the gradient norm passes the convergence test.
+NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& L, int it,
+                             bool gradKept) {
     const int tid = threadIdx.x, N = v.N;
     double nn;
     if (gradKept) {
@@ -261,13 +262,20 @@ NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L,
     if (tid == 0) { I.sc->numIter = it; I.sc->regularized = 0; }
     if (sqrt(nn) < kStatTol) {
         if (tid == 0) I.sc->status = ST_OPTIMAL;
-        return;
+        return false;
     }
+    return true;
+}
 
+// Newton Hessian block rows of the stages whose active set changed, every
+// WAVES-th block row per wavefront; slices: 360 doubles of LDS per wavefront.
+template <int WAVES>
+NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices) {
+    const int tid = threadIdx.x, N = v.N;
     const int w = tid >> 6, lane = tid & 63;
-    double* Cs = L.buf + w * (2 * NX * NZ);
+    double* Cs = slices + w * (2 * NX * NZ);
     double* Zs = Cs + NX * NZ;
-    for (int k = w; k < N; k += kStageThreads / kWave) {
+    for (int k = w; k < N; k += WAVES) {
         const bool ck = I.chg[k] != 0, cn = I.chg[k + 1] != 0;
         if (!(ck || cn)) continue;
         const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);
@@ -329,6 +337,11 @@ NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L,
     }
 }
 
+NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it,
+                           bool gradKept = false) {
+    if (setup_gradient(v, I, L, it, gradKept))
+        assemble_hessian<kStageThreads / kWave>(v, I, L.buf);
+}
 
 // ------------------------------------------------------------------------
 // The gradient-bisection step-length search (dual_qp.c:1341-1470) as a state
@@ -372,6 +385,24 @@ NMPC_DEV void advance(Bisection& s, double slope, double normal) {
     settle(s);
 }
 
+// The state after a trial that did not end the search and whose slope was
+// negative / positive: advance() without the tests a real slope needs.
+NMPC_DEV void advance_assuming(Bisection& s, bool negative) {
+    if (s.phase == 0) {
+        if (negative) { s.phase = 1; settle(s); return; }
+        s.aMin = s.aMax;
+        s.aMax *= kLsIncrease;
+        if (s.aMax > kLsMaxStep) { s.alpha = s.aMin; s.done = true; return; }
+        ++s.it;
+        if (s.it >= kMaxLsRefine) s.phase = 1;
+    } else {
+        s.aMid = 0.5 * (s.aMin + s.aMax);
+        if (negative) s.aMax = s.aMid; else s.aMin = s.aMid;
+        ++s.it;
+    }
+    settle(s);
+}
+
 // Commit of a step whose clipped point and gaps are already in z and y (the last
 // value trial ran at the same step length and nothing has touched them since):
 // what is left is the unclipped point, the linear term, the offsets and the
@@ -401,7 +432,7 @@ NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, double a, con
 // objective of the value trial that z and y still hold, or is null.
 NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, double alpha,
                           int lsIter, int nextIt, const double* keptObjective = nullptr,
-                          bool gradKept = false) {
+                          bool gradKept = false, bool withHessian = true) {
     const int tid = threadIdx.x, n = NX * v.N;
     for (int r = tid; r < n; r += kStageThreads) {
         double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
@@ -423,7 +454,8 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
     }
     if (nextIt <= kMaxIter) {
         __syncthreads();
-        newton_setup(v, I, L, nextIt, gradKept && keptObjective);
+        if (withHessian) newton_setup(v, I, L, nextIt, gradKept && keptObjective);
+        else setup_gradient(v, I, L, nextIt, gradKept && keptObjective);
     }
 }
 
@@ -507,15 +539,21 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
 // k_line_search_tail (kTailElems values of each vector per thread).
 constexpr int kTailThreads = 1024;
 constexpr int kTailElems = 2;
-constexpr int kTailPoints = 3;      // trial steps evaluated per round: one + both successors
-constexpr int kTailMaxHorizon = 135;
+constexpr int kTailDepth = 3;       // bisection levels settled per round
+constexpr int kTailPoints = (1 << kTailDepth) - 1;  // trial steps per round: a binary tree of outcomes
+constexpr int kTailMaxHorizon = 106;    // the tree's trial points and slope terms fill the 160 KB of LDS
+// Slope-term lists are accumulated side by side, one lane each; a stride that is
+// 5 mod 32 doubles keeps the lanes on different LDS banks.
+NMPC_DEV int tail_term_stride(int n) { return n + ((5 - n % 32) + 32) % 32; }
+static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon + 32) * 8 + 64 <= 160 * 1024,
+              "trial points and slope terms must fit LDS");
 static_assert(NZ * (kTailMaxHorizon + 1) <= kTailElems * kTailThreads, "stage vectors must fit");
 static_assert(NX / 2 * kTailMaxHorizon <= kTailThreads, "two gradient rows per thread");
 NMPC_DEV bool tail_capable(const BatchView& v) {
     return v.tailList != nullptr && v.N <= kTailMaxHorizon;
 }
 inline size_t tail_lds_bytes(int N) {
-    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N) * sizeof(double) + 64;
+    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(double) + 64;
 }
 }  // namespace
 
@@ -671,16 +709,19 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 // points are made of stay in registers, trial points and slope terms live in
 // LDS only (the reference's scratch copies of them, zVecTmp and y, are
 // rewritten by the commit anyway), and each round evaluates the next trial step
-// together with both of its possible successors, so a round settles two
-// bisection levels for one ordered accumulation.  Leaves the step length and
-// trial count in the instance's scalars for k_line_search_commit.
+// together with every step that can follow it within kTailDepth levels (a
+// binary tree: each trial is either left or right of the root of the slope),
+// so one round of ordered accumulations, which costs 8 microseconds however
+// many run side by side, settles kTailDepth levels.  Leaves the step length
+// and trial count in the instance's scalars for k_line_search_commit.
 __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, int nextIt) {
     extern __shared__ double lds_raw[];
     const int tid = threadIdx.x;
     const int N = v.N, n = NX * N, eEnd = NZ * N + NX, E = NZ * (N + 1);
     double* tp = lds_raw;                                   // [points][E] clipped trial points
-    double* terms = lds_raw + kTailPoints * E;              // [points][n] slope terms
-    double* slopes = terms + kTailPoints * n;               // [points]
+    double* terms = lds_raw + kTailPoints * E;              // [points][stride >= n] slope terms
+    const int ts = tail_term_stride(n);
+    double* slopes = terms + kTailPoints * ts;              // [points]
     // gradient rows: thread t < 6 N owns rows h and h + 6 of block t / 6
     const int rk = tid / (NX / 2), rh = tid % (NX / 2);
     const bool rowOn = rk < N;
@@ -717,14 +758,25 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
         }
         settle(bs);
         while (!bs.done) {
-            // this round's trial steps: the next one and its successor on either outcome
-            double at[kTailPoints];
-            Bisection neg = bs, pos = bs;
-            at[0] = trial_alpha(bs);
-            advance(neg, -1e300, normal);
-            advance(pos, 1e300, normal);
-            at[1] = neg.done ? at[0] : trial_alpha(neg);
-            at[2] = pos.done ? at[0] : trial_alpha(pos);
+            // this round's trial steps, heap order: node 1 is the next trial, nodes 2i
+            // and 2i+1 the trials after node i when its slope is negative / positive
+            double at[kTailPoints + 1];
+            {
+                Bisection st[kTailPoints + 1];
+                st[1] = bs;
+#pragma unroll
+                for (int i = 1; i <= kTailPoints; i++) {
+                    at[i] = st[i].done ? at[1] : trial_alpha(st[i]);
+                    if (2 * i + 1 <= kTailPoints) {
+                        st[2 * i] = st[i];
+                        st[2 * i + 1] = st[i];
+                        if (!st[i].done) {
+                            advance_assuming(st[2 * i], true);
+                            advance_assuming(st[2 * i + 1], false);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int m = 0; m < kTailElems; m++) {
                 const int e = tid + m * kTailThreads;
@@ -732,7 +784,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
 #pragma unroll
                     for (int p = 0; p < kTailPoints; p++) {
                         double y0, y1;
-                        tp[p * E + e] = clip_gap(zu[m] + at[p] * dzv[m], lo[m], up[m], &y0, &y1);
+                        tp[p * E + e] = clip_gap(zu[m] + at[p + 1] * dzv[m], lo[m], up[m], &y0, &y1);
                     }
                 }
             }
@@ -753,20 +805,24 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
                     b2 += resB;
                     a -= tp[p * E + sn * NZ + rh];
                     b2 -= tp[p * E + sn * NZ + rh + NX / 2];
-                    terms[p * n + rk * NX + rh] = a * dlA;
-                    terms[p * n + rk * NX + rh + NX / 2] = b2 * dlB;
+                    terms[p * ts + rk * NX + rh] = a * dlA;
+                    terms[p * ts + rk * NX + rh + NX / 2] = b2 * dlB;
                 }
             }
             __syncthreads();
-            if (tid < kTailPoints) slopes[tid] = accumulate_in_order<16>(0., terms + tid * n, n);
+            if (tid < kTailPoints) slopes[tid] = accumulate_in_order<16>(0., terms + tid * ts, n);
             __syncthreads();
-            const double s0 = slopes[0], sNeg = slopes[1], sPos = slopes[2];
-            __syncthreads();
-            const int phase0 = bs.phase;
-            advance(bs, s0, normal);
-            if (!bs.done) {
-                const bool tookNeg = phase0 == 0 ? (s0 / normal < 0.) : !(s0 > 0);
-                advance(bs, tookNeg ? sNeg : sPos, normal);
+            // slopes stays untouched until the next round's accumulation, two
+            // barriers from here
+            int node = 1;
+#pragma unroll
+            for (int level = 0; level < kTailDepth; level++) {
+                if (!bs.done) {
+                    const double sv = slopes[node - 1];
+                    const bool neg = bs.phase == 0 ? (sv / normal < 0.) : !(sv > 0);
+                    advance(bs, sv, normal);
+                    node = 2 * node + (neg ? 0 : 1);
+                }
             }
         }
         if (tid == 0) {
@@ -789,8 +845,19 @@ __global__ __launch_bounds__(kStageThreads) void k_line_search_commit(BatchView 
         for (int s = tid; s <= v.N; s += kStageThreads) L.chg[s] = 0;
         __syncthreads();
         if (tid == 0) I.sc->lsDeferred = 0;
-        commit_step(v, I, L, alpha, lsIter, nextIt);
+        commit_step(v, I, L, alpha, lsIter, nextIt, nullptr, false, false);
         __syncthreads();
+    }
+}
+
+// Newton Hessian block rows of the same instances, sixteen wavefronts each: a
+// lone instance's block rows are a latency chain per wavefront.
+__global__ __launch_bounds__(kTailThreads) void k_line_search_hessian(BatchView v, int nextIt) {
+    extern __shared__ double lds_raw[];
+    const int count = v.tailCount[nextIt - 2];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        Inst I = instance(v, v.tailList[item]);
+        if (I.sc->status == ST_RUNNING) assemble_hessian<kTailThreads / kWave>(v, I, lds_raw);
     }
 }
 
@@ -812,6 +879,9 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     hipLaunchKernelGGL(k_line_search_tail, dim3(grid), dim3(kTailThreads), lds, s, v, next_it);
     hipLaunchKernelGGL(k_line_search_commit, dim3(grid), dim3(kStageThreads), stage_lds_bytes(v.N), s,
                        v, next_it);
+    if (next_it <= kMaxIter)
+        hipLaunchKernelGGL(k_line_search_hessian, dim3(grid), dim3(kTailThreads),
+                           (kTailThreads / kWave) * 2 * NX * NZ * sizeof(double), s, v, next_it);
 }
 
 }  // namespace nmpc
