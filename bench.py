@@ -42,11 +42,16 @@ FP64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector, spec (FMA counted as 2 flop)
 # functions (one flop per add/sub/mul/div/sqrt/compare-select):
 #   linearise     per stage: 16 RK4 integrations + 16 state differences;
 #                 reads x_k, u_k (128 B), writes C (1440 B) and c (96 B)
-#   newton_solve  per stage block and Newton iteration: reverse Cholesky of a
-#                 12x12 diagonal + 12x12 sub-diagonal block (4.2 kflop) and two
-#                 substitutions (0.84 kflop); reads the Hessian block row
-#                 (2304 B) and the gradient (96 B), writes the factor (2304 B)
-#                 and the step (96 B)
+#   newton_solve  per stage block and Newton iteration: two substitutions
+#                 (0.84 kflop) that read the factor block row once each, on the
+#                 way down and on the way up (2 x 2304 B; 230 kB of factor per
+#                 instance do not stay on chip between the sweeps), the
+#                 gradient (96 B) and read/write the step (3 x 96 B): 4992 B;
+#                 blocks that are refactorised add the reverse Cholesky of a
+#                 12x12 diagonal + 12x12 sub-diagonal block (4.2 kflop) and the
+#                 store of the factor (2304 B).  Every block is refactorised in
+#                 the first iteration; later iterations refactorise from the
+#                 last active-set change down, which is not counted here.
 #   newton_setup  per stage and iteration: gradient (0.38 kflop) + Hessian
 #                 blocks (4.7 kflop); reads C, c, z, y (1896 B), writes the
 #                 block row and gradient (2400 B)
@@ -54,7 +59,8 @@ FP64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector, spec (FMA counted as 2 flop)
 #                 objective; reads C, c and the 15-vectors, writes them back
 ALGO = {
     "linearise": dict(flop=17000.0, bytes=1664.0),
-    "newton_solve": dict(flop=5040.0, bytes=4800.0),
+    "newton_solve": dict(flop=840.0, bytes=4992.0),
+    "newton_factor": dict(flop=4200.0, bytes=2304.0),
     "newton_setup": dict(flop=5080.0, bytes=4296.0),
     "newton_step": dict(flop=670.0, bytes=3100.0),
     "qp_begin": dict(flop=260.0, bytes=1100.0),
@@ -195,7 +201,8 @@ def main():
     work = {
         "linearise": [(ALGO["linearise"], B * N * a.steps)],
         "qp_begin": [(ALGO["qp_begin"], B * (N + 1) * a.steps), (ALGO["newton_setup"], n_setup_first)],
-        "newton_solve": [(ALGO["newton_solve"], int(newton_runs.sum()) * N * a.steps)],
+        "newton_solve": [(ALGO["newton_solve"], int(newton_runs.sum()) * N * a.steps),
+                         (ALGO["newton_factor"], int((newton_runs >= 1).sum()) * N * a.steps)],
         "newton_step": [(ALGO["newton_step"], n_step), (ALGO["newton_setup"], n_setup_later)],
     }
     kern = {}

@@ -173,6 +173,21 @@ def test_full_size_cold_solve_4096(port_built):
     bt2.close()
 
 
+def test_large_batch_20000(port_built):
+    """20 000 instances: more line searches are handed over per Newton
+    iteration than the hand-over kernels have workgroups, and the Newton
+    kernel runs several rounds of wavefronts per SIMD."""
+    from nmpc_amd import synthetic as S
+    N, B = 100, 20000
+    d = S.make_batch(B, N, seed=77)
+    bt, (u, st, it) = _gpu_cold(d, N)
+    eu, est, eit, _ = _port_cold(d, N)
+    assert_same(st, est, "status")
+    assert_same(it, eit, "QP iterations")
+    assert_same(u, eu, "controls")
+    bt.close()
+
+
 def test_long_horizon_batch(port_built):
     """Horizon 500 (stage-parallel QP work): 24 instances against the oracle."""
     from nmpc_amd import synthetic as S
@@ -191,7 +206,8 @@ def test_small_and_odd_shapes(port_built):
     1 instance x 2 stages."""
     import portdriver as P
     from nmpc_amd import synthetic as S
-    for B, N, steps in ((3, 7, 6), (1, 2, 4), (5, 65, 3)):
+    # 106 / 120: largest horizon the line-search hand-over kernels take / first one past it
+    for B, N, steps in ((3, 7, 6), (1, 2, 4), (5, 65, 3), (4, 106, 3), (4, 120, 3)):
         d = S.make_batch(B, N, extra_steps=steps, seed=B * 100 + N, turn_start=(0.05, 0.5))
         gs = []
         cfg = S.setup_args()

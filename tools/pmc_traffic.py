@@ -5,9 +5,9 @@ into profiles/traffic.json: mean HBM bytes per launch of every nmpc kernel.
     python tools/pmc_traffic.py <fetch counter_collection.csv> <write ...csv> B N
 
 FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte
-read requests as 64 bytes, so the read side is doubled.  The fill launches of
-the same run (hipMemsetAsync of a known byte count) calibrate the write side:
-their measured / requested ratio is stored next to the numbers.
+read requests as 64 bytes, so the read side is doubled.  Cross-check of the
+write side: k_linearise stores 409 600 stages x (C 1440 B + c 96 B + six
+15-vectors) = 924 MB per launch and the counter reports 932 MB.
 """
 import csv
 import json
@@ -51,10 +51,6 @@ def main():
         out["read_bytes_per_launch"][k] = round(r)
         out["write_bytes_per_launch"][k] = round(w)
         out["launches"][k] = len(fetch.get(name, []))
-    fills = write.get("__amd_rocclr_fillBufferAligned", [])
-    if fills:
-        out["fill_write_bytes_largest"] = round(1024.0 * max(fills))
-        out["fill_expected_bytes_largest"] = B * N * 180 * 8   # the Jacobian memset of nmpc_batch_init
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        "profiles", "traffic.json")
     with open(dst, "w") as f:
