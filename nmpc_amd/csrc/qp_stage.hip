@@ -36,10 +36,11 @@ namespace nmpc {
 namespace {
 
 constexpr int kStageThreads = 256;
-// k_qp_begin waits on memory most of the time: eight resident wavefronts per
-// SIMD (64 registers per lane, no spills) measured 15 % faster than four.
-// k_newton_step needs about 120 registers; capping it lower spills and is slower.
-#define NMPC_BEGIN_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+// k_qp_begin waits on memory most of the time: seven resident wavefronts per
+// SIMD (72 registers per lane, no spills) measured 20 % faster than four; eight
+// spill.  k_newton_step needs about 120 registers; capping it lower spills and
+// is slower.
+#define NMPC_BEGIN_OCC __attribute__((amdgpu_waves_per_eu(7, 7)))
 constexpr int kStageChunk = 64;                 // stage slots whose z, q sit in LDS at once
 constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920: z + q, reused as sum buffer
 
@@ -275,26 +276,48 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
     const int w = tid >> 6, lane = tid & 63;
     double* Cs = slices + w * (2 * NX * NZ);
     double* Zs = Cs + NX * NZ;
-    for (int k = w; k < N; k += WAVES) {
-        const bool ck = I.chg[k] != 0, cn = I.chg[k + 1] != 0;
-        if (!(ck || cn)) continue;
+    // The Jacobian entries and gaps of the next block row to assemble are fetched
+    // while the current one is worked on.
+    struct Fetched { double c[3], y[4]; };
+    auto needed = [&](int k) { return k < N && (I.chg[k] != 0 || I.chg[k + 1] != 0); };
+    auto fetch = [&](int k, Fetched& f) {
         const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);
-        const double* Hn = stage_hessian(v, k + 1);
         const double* Cg = I.C + (size_t)s * (NX * NZ);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int e = lane + t * kWave;
+            f.c[t] = (e < NX * NZ) ? Cg[e] : 0.;
+        }
+        const int ly = lane < NZ ? lane : 0, lx = lane < NX ? lane : 0;
+        f.y[0] = I.y[2 * s * NZ + 2 * ly];
+        f.y[1] = I.y[2 * s * NZ + 2 * ly + 1];
+        f.y[2] = I.y[2 * sn * NZ + 2 * lx];
+        f.y[3] = I.y[2 * sn * NZ + 2 * lx + 1];
+    };
+    int k = w;
+    while (k < N && !needed(k)) k += WAVES;
+    Fetched cur{}, nxt{};
+    if (k < N) fetch(k, cur);
+    while (k < N) {
+        int kn = k + WAVES;
+        while (kn < N && !needed(kn)) kn += WAVES;
+        if (kn < N) fetch(kn, nxt);
+        const bool ck = I.chg[k] != 0;
+        const double* Hn = stage_hessian(v, k + 1);
         // free columns of stage k; fixed states of stage k+1
-        bool fr = false, fx = false;
-        if (lane < NZ)
-            fr = (I.y[2 * s * NZ + 2 * lane] <= kEqTol) &&
-                 (I.y[2 * s * NZ + 2 * lane + 1] <= kEqTol);
-        if (lane < NX)
-            fx = (I.y[2 * sn * NZ + 2 * lane] >= kEqTol) ||
-                 (I.y[2 * sn * NZ + 2 * lane + 1] >= kEqTol);
+        const bool fr = lane < NZ && cur.y[0] <= kEqTol && cur.y[1] <= kEqTol;
+        const bool fx = lane < NX && (cur.y[2] >= kEqTol || cur.y[3] >= kEqTol);
         const unsigned long long freeMask = __ballot(fr);
         const unsigned long long fixMask = __ballot(fx);
-        for (int e = lane; e < NX * NZ; e += kWave) {
-            Cs[e] = Cg[e];
-            const int l = e / NX, j = e % NX;
-            Zs[e] = Cg[j * NZ + l] / v.H[l];
+        // C_k and C_k' P_k (entry (i, l) of C goes to (l, i) of the product)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int e = lane + t * kWave;
+            if (e < NX * NZ) {
+                const int i = e / NZ, l = e % NZ;
+                Cs[e] = cur.c[t];
+                Zs[l * NX + i] = cur.c[t] / v.H[l];
+            }
         }
         // this wavefront's LDS writes land before its reads below
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -334,6 +357,8 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
         // reads done before the next block row overwrites the slice
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        k = kn;
+        cur = nxt;
     }
 }
 
