@@ -187,6 +187,23 @@ int nmpc_batch_get_global(nmpc_batch_t *b, uint32_t instance, real_t *out);
 int nmpc_batch_get_solver_info(nmpc_batch_t *b, uint32_t instance, int32_t info[6],
                                real_t *alpha);
 
+/* Plant roll-forward beside the controllers, for closed-loop studies that stay
+ * on the GPU: per instance what nmpc_fixedwingdynamics_set_state / _get_state /
+ * _integrate do for the one controller (c/cnmpc.cpp:140-180, with the state
+ * model and RK4 step of ccs-c66x/cnmpc.c:320-400).
+ *   state     [instances][13]
+ *   controls  [instances][3], or NULL for the controls nmpc_batch_get_controls
+ *             would return (last good controls of every instance)
+ *   wind      [instances][3] acting on the plant, or NULL for the wind estimate
+ *             given to nmpc_batch_set_wind_velocity
+ * nmpc_batch_feedback_step_from_plant is nmpc_batch_feedback_step with the
+ * plant states as measurements. */
+int nmpc_batch_plant_set_state(nmpc_batch_t *b, const real_t *state);
+int nmpc_batch_plant_get_state(nmpc_batch_t *b, real_t *state);
+int nmpc_batch_plant_integrate(nmpc_batch_t *b, real_t dt, const real_t *controls,
+                               const real_t *wind);
+int nmpc_batch_feedback_step_from_plant(nmpc_batch_t *b);
+
 /* Per-kernel timing with HIP events on the batch's stream.  kernel ids: */
 enum {
     NMPC_K_LINEARISE = 0, NMPC_K_QP_BEGIN, NMPC_K_LINE_SEARCH_TAIL, NMPC_K_NEWTON_SOLVE,

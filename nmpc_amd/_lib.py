@@ -80,6 +80,10 @@ PROTOTYPES = {
     "nmpc_batch_feedback_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nmpc_batch_get_controls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nmpc_batch_update_horizon": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nmpc_batch_plant_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nmpc_batch_plant_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nmpc_batch_plant_integrate": (C.c_int, [C.c_void_p, REAL, C.c_void_p, C.c_void_p]),
+    "nmpc_batch_feedback_step_from_plant": (C.c_int, [C.c_void_p]),
     "nmpc_batch_instances": (C.c_uint32, [C.c_void_p]),
     "nmpc_batch_horizon": (C.c_uint32, [C.c_void_p]),
     "nmpc_batch_get_stage": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, PREAL]),

@@ -128,6 +128,29 @@ class Batch:
         self._ck(self.lib.nmpc_batch_update_horizon(self.h, a.ptr))
         self._keep.append(a)
 
+    # -- plant roll-forward (closed loop on the device) ---------------------
+    def plant_set_state(self, states):
+        a = _Arg(states, (self.B, 13))
+        self._ck(self.lib.nmpc_batch_plant_set_state(self.h, a.ptr))
+        self._keep.append(a)
+
+    def plant_state(self):
+        x = np.zeros((self.B, 13))
+        self._ck(self.lib.nmpc_batch_plant_get_state(self.h, x.ctypes.data_as(C.c_void_p)))
+        return x
+
+    def plant_integrate(self, dt, controls=None, wind=None):
+        """One RK4 step of every simulated vehicle.  controls None: the last good
+        controls of each controller; wind None: the controllers' wind estimate."""
+        ac = _Arg(controls, (self.B, 3)) if controls is not None else None
+        aw = _Arg(wind, (self.B, 3)) if wind is not None else None
+        self._ck(self.lib.nmpc_batch_plant_integrate(
+            self.h, float(dt), ac.ptr if ac else None, aw.ptr if aw else None))
+        self._keep += [a for a in (ac, aw) if a]
+
+    def solve_from_plant(self):
+        self._ck(self.lib.nmpc_batch_feedback_step_from_plant(self.h))
+
     def reset(self):
         """Cold-start state again (see nmpc_batch_reset); weights and bounds stay."""
         self._ck(self.lib.nmpc_batch_reset(self.h))

@@ -96,6 +96,8 @@ struct nmpc_batch {
     // clear itself is postponed until something is about to read or partly
     // overwrite them, and dropped when every stage is linearised first.
     bool jacobians_zero_pending = false;
+    double* plant = nullptr;    // [B][13] simulated vehicle states (nmpc_batch_plant_*)
+    double* plant_next = nullptr;   // output of the next roll-forward step, then swapped
     bool profiling = false;
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
@@ -276,6 +278,8 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
     for (auto ev : b->free_events) (void)hipEventDestroy(ev);
     b->in_refs.release(); b->in_meas.release(); b->in_wind.release();
     b->out_u.release(); b->out_status.release(); b->out_iters.release(); b->scratch.release();
+    if (b->plant) (void)hipFree(b->plant);
+    if (b->plant_next) (void)hipFree(b->plant_next);
     if (b->arena) (void)hipFree(b->arena);
     if (b->own_stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -440,6 +444,78 @@ int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
     TRY(timed(b, NMPC_K_LINEARISE, [&] { launch_linearise(v, v.N - 1, 1, b->stream); }));
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
+}
+
+// ---- plant roll-forward --------------------------------------------------------
+static int plant_buffer(nmpc_batch* b) {
+    if (b->plant) return 0;
+    const size_t bytes = (size_t)b->v.B * 13 * sizeof(double);
+    HIP_TRY(hipMalloc((void**)&b->plant, bytes));
+    HIP_TRY(hipMalloc((void**)&b->plant_next, bytes));
+    HIP_TRY(hipMemsetAsync(b->plant, 0, bytes, b->stream));
+    return 0;
+}
+
+int nmpc_batch_plant_set_state(nmpc_batch_t* b, const real_t* state) {
+    if (!b || !state) return fail(NMPC_E_ARG, "nmpc_batch_plant_set_state: null argument");
+    TRY(use_device(b));
+    TRY(plant_buffer(b));
+    HIP_TRY(hipMemcpyAsync(b->plant, state, (size_t)b->v.B * 13 * sizeof(double), hipMemcpyDefault,
+                           b->stream));
+    if (!is_device_pointer(state)) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int nmpc_batch_plant_get_state(nmpc_batch_t* b, real_t* state) {
+    if (!b || !state) return fail(NMPC_E_ARG, "nmpc_batch_plant_get_state: null argument");
+    TRY(use_device(b));
+    TRY(plant_buffer(b));
+    HIP_TRY(hipMemcpyAsync(state, b->plant, (size_t)b->v.B * 13 * sizeof(double), hipMemcpyDefault,
+                           b->stream));
+    if (!is_device_pointer(state)) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int nmpc_batch_plant_integrate(nmpc_batch_t* b, real_t dt, const real_t* controls,
+                               const real_t* wind) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    TRY(use_device(b));
+    TRY(plant_buffer(b));
+    const size_t B = (size_t)b->v.B;
+    const void* du = nullptr;
+    const void* dw = b->v.wind;
+    bool host = false;
+    if (controls) {
+        host = host || !is_device_pointer(controls);
+        TRY(stage_in(b, b->in_meas, controls, B * 3 * sizeof(double), &du));
+    } else {
+        // the controls every instance would report now
+        TRY(b->out_u.reserve(B * 3 * sizeof(double)));
+        TRY(b->out_status.reserve(B * sizeof(int)));
+        TRY(b->out_iters.reserve(B * sizeof(int)));
+        TRY(timed(b, NMPC_K_OTHER, [&] {
+            launch_gather_results(b->v, (double*)b->out_u.ptr, (int*)b->out_status.ptr,
+                                  (int*)b->out_iters.ptr, b->stream);
+        }));
+        du = b->out_u.ptr;
+    }
+    if (wind) {
+        host = host || !is_device_pointer(wind);
+        TRY(stage_in(b, b->in_wind, wind, B * 3 * sizeof(double), &dw));
+    }
+    TRY(timed(b, NMPC_K_OTHER, [&] {
+        launch_rk4_free((long)B, b->plant, (const double*)du, (const double*)dw, dt, b->plant_next,
+                        b->stream);
+    }));
+    std::swap(b->plant, b->plant_next);
+    if (host) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int nmpc_batch_feedback_step_from_plant(nmpc_batch_t* b) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    if (!b->plant) return fail(NMPC_E_STATE, "nmpc_batch_feedback_step_from_plant before nmpc_batch_plant_set_state");
+    return nmpc_batch_feedback_step(b, b->plant);
 }
 
 uint32_t nmpc_batch_instances(const nmpc_batch_t* b) { return b ? (uint32_t)b->v.B : 0; }

@@ -325,6 +325,55 @@ def test_piecewise_reference_loading_and_reset():
     bt0.close()
 
 
+def test_closed_loop_with_device_plant(port_built):
+    """Controllers and simulated vehicles both on the GPU: feedback on the plant
+    state, one RK4 step of the plant under the returned controls and a wind
+    that differs from the estimate, horizon shift -- against the same loop
+    built from the CPU oracle's controller and RK4."""
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B, steps, dt = 30, 6, 8, 1.0 / 50.0
+    d = S.make_batch(B, N, extra_steps=steps, seed=404, turn_start=(0.05, 0.4))
+    rng = np.random.default_rng(9)
+    true_wind = d["wind"] + rng.normal(0.0, 1.0, (B, 3))
+    cfg = S.setup_args()
+
+    bt = Batch(B, N)
+    bt.setup(**cfg)
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    bt.plant_set_state(d["meas"][:, 0])
+    gu, gx = [], []
+    for k in range(steps):
+        bt.prepare()
+        bt.solve_from_plant()
+        u, st, it = bt.get_controls()
+        bt.plant_integrate(dt, wind=true_wind)
+        bt.update_horizon(d["refs"][:, N + 1 + k])
+        gu.append(u)
+        gx.append(bt.plant_state())
+    bt.close()
+
+    for b in range(B):
+        c = P.Port(N)
+        c.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        c.init()
+        c.set_wind(d["wind"][b])
+        for i in range(N + 1):
+            c.set_reference(d["refs"][b, i], i)
+        x = d["meas"][b, 0].copy()
+        for k in range(steps):
+            c.feedback(x)
+            u, _ = c.controls()
+            x = P.rk4(x, u, true_wind[b], dt)
+            c.update_horizon(d["refs"][b, N + 1 + k])
+            assert_same(gu[k][b], np.asarray(u), "controls, instance %d step %d" % (b, k))
+            assert_same(gx[k][b], np.asarray(x), "plant state, instance %d step %d" % (b, k))
+
+
 def test_error_reporting():
     from nmpc_amd import _lib
     from nmpc_amd import synthetic as S
