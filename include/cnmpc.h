@@ -154,6 +154,15 @@ int nmpc_batch_set_reference_points(nmpc_batch_t *b, const real_t *refs,
 /* nmpc_preparation_step: no work (ccs-c66x/cnmpc.c:950-951). */
 int nmpc_batch_preparation_step(nmpc_batch_t *b);
 
+/* Re-linearisation of every stage about the stored reference trajectory with
+ * the current wind estimate and control bounds: what calling
+ * nmpc_set_reference_point again with the same points for i = 0..horizon does
+ * (ccs-c66x/cnmpc.c:1022-1080), without moving the points.  The reference's
+ * preparation step is empty (ccs-c66x/cnmpc.c:950-951, src/ocp.cpp:245-250,
+ * 315-322); this is the work its comments assign to it, offered separately so
+ * that nmpc_batch_preparation_step stays a drop-in. */
+int nmpc_batch_relinearise(nmpc_batch_t *b);
+
 /* nmpc_feedback_step per instance; measurement: [instances][13]
  * (ccs-c66x/cnmpc.c:953-956).  Asynchronous. */
 int nmpc_batch_feedback_step(nmpc_batch_t *b, const real_t *measurement);

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "nmpc_batch_set_reference_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32,
                                                   C.c_uint32]),
     "nmpc_batch_preparation_step": (C.c_int, [C.c_void_p]),
+    "nmpc_batch_relinearise": (C.c_int, [C.c_void_p]),
     "nmpc_batch_feedback_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nmpc_batch_get_controls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nmpc_batch_update_horizon": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -100,6 +100,11 @@ class Batch:
     def prepare(self):
         self._ck(self.lib.nmpc_batch_preparation_step(self.h))
 
+    def relinearise(self):
+        """Every stage linearised again about the stored references at the current
+        wind estimate (see nmpc_batch_relinearise)."""
+        self._ck(self.lib.nmpc_batch_relinearise(self.h))
+
     def solve(self, measurement):
         a = _Arg(measurement, (self.B, 13))
         self._ck(self.lib.nmpc_batch_feedback_step(self.h, a.ptr))

@@ -376,6 +376,16 @@ int nmpc_batch_preparation_step(nmpc_batch_t* b) {
     return 0;
 }
 
+int nmpc_batch_relinearise(nmpc_batch_t* b) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    if (!b->initialised) return fail(NMPC_E_STATE, "nmpc_batch_relinearise before nmpc_batch_init");
+    TRY(use_device(b));
+    sync_config(b);
+    b->jacobians_zero_pending = false;      // every stage is rewritten
+    TRY(timed(b, NMPC_K_LINEARISE, [&] { launch_linearise(b->v, 0, b->v.N, b->stream); }));
+    return 0;
+}
+
 int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     if (!b || !measurement) return fail(NMPC_E_ARG, "nmpc_batch_feedback_step: null argument");
     if (!b->initialised) return fail(NMPC_E_STATE, "nmpc_batch_feedback_step before nmpc_batch_init");

@@ -374,6 +374,58 @@ def test_closed_loop_with_device_plant(port_built):
             assert_same(gx[k][b], np.asarray(x), "plant state, instance %d step %d" % (b, k))
 
 
+def test_relinearise_matches_resetting_every_reference_point(port_built):
+    """nmpc_batch_relinearise after a wind change and two horizon shifts equals
+    calling set_reference_point again for every stored point on the oracle."""
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B, steps = 25, 5, 5
+    d = S.make_batch(B, N, extra_steps=steps, seed=515, turn_start=(0.05, 0.3))
+    cfg = S.setup_args()
+    wind2 = d["wind"] + np.array([2.0, -1.5, 0.5])
+    relin_at = 2
+
+    bt = Batch(B, N)
+    bt.setup(**cfg)
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    got = []
+    for k in range(steps):
+        if k == relin_at:
+            bt.set_wind_velocity(wind2)
+            bt.relinearise()
+        bt.solve(d["meas"][:, k])
+        got.append(bt.get_controls())
+        bt.update_horizon(d["refs"][:, N + 1 + k])
+    gs = [bt.stages(b) for b in range(B)]
+    gg = [bt.globals_(b) for b in range(B)]
+    bt.close()
+
+    for b in range(B):
+        c = P.Port(N)
+        c.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        c.init()
+        c.set_wind(d["wind"][b])
+        for i in range(N + 1):
+            c.set_reference(d["refs"][b, i], i)
+        for k in range(steps):
+            if k == relin_at:
+                c.set_wind(wind2[b])
+                for i in range(N + 1):
+                    c.set_reference(d["refs"][b, k + i], i)
+            c.feedback(d["meas"][b, k])
+            u, st = c.controls()
+            assert_same(got[k][0][b], u, "controls, instance %d step %d" % (b, k))
+            assert got[k][1][b] == st
+            assert got[k][2][b] == c.num_iter()
+            c.update_horizon(d["refs"][b, N + 1 + k])
+        assert_same(gs[b], c.stages(), "stage records, instance %d" % b)
+        assert_same(gg[b], c.globals_(), "solver state, instance %d" % b)
+
+
 def test_error_reporting():
     from nmpc_amd import _lib
     from nmpc_amd import synthetic as S
