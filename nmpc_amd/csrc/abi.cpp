@@ -96,6 +96,12 @@ struct nmpc_batch {
     // clear itself is postponed until something is about to read or partly
     // overwrite them, and dropped when every stage is linearised first.
     bool jacobians_zero_pending = false;
+    // Likewise for nmpc_batch_reset: the stage vectors zLow .. y are logically
+    // zero after it, but nmpc_batch_init rewrites six of the nine, the first
+    // feedback step rewrites z and y, and the trial-point scratch is never
+    // looked at; clears happen only where an earlier reader turns up.
+    bool stage_zero_pending = false;    // zLow, zUpp, q, z, qStep, zUnc, dz, tmp, y
+    bool zy_zero_pending = false;       // z, y only (after nmpc_batch_init)
     double* plant = nullptr;    // [B][13] simulated vehicle states (nmpc_batch_plant_*)
     double* plant_next = nullptr;   // output of the next roll-forward step, then swapped
     bool profiling = false;
@@ -177,6 +183,20 @@ void sync_config(nmpc_batch* b) {
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Carries out the postponed clears of the stage vectors.
+int materialise_stage_vectors(nmpc_batch* b) {
+    const BatchView& v = b->v;
+    const size_t vec = (size_t)v.B * (v.N + 1) * 15 * sizeof(double);
+    if (b->stage_zero_pending) {
+        HIP_TRY(hipMemsetAsync(v.zLow, 0, (size_t)((char*)v.p - (char*)v.zLow), b->stream));
+    } else if (b->zy_zero_pending) {
+        HIP_TRY(hipMemsetAsync(v.z, 0, vec, b->stream));
+        HIP_TRY(hipMemsetAsync(v.y, 0, 2 * vec, b->stream));
+    }
+    b->stage_zero_pending = b->zy_zero_pending = false;
+    return 0;
+}
 
 // Carries out the postponed clear of C and c.
 int materialise_jacobians(nmpc_batch* b) {
@@ -289,7 +309,12 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
 int nmpc_batch_reset(nmpc_batch_t* b) {
     if (!b) return fail(NMPC_E_ARG, "null batch");
     TRY(use_device(b));
-    HIP_TRY(hipMemsetAsync(b->arena, 0, b->reset_bytes, b->stream));
+    const BatchView& v = b->v;
+    char* base = (char*)b->arena;
+    HIP_TRY(hipMemsetAsync(base, 0, (size_t)((char*)v.zLow - base), b->stream));
+    HIP_TRY(hipMemsetAsync(v.p, 0, (size_t)(base + b->reset_bytes - (char*)v.p), b->stream));
+    b->stage_zero_pending = true;
+    b->zy_zero_pending = false;
     b->v.head = b->v.xhead = b->v.lhead = 0;
     b->initialised = false;
     return 0;
@@ -328,6 +353,10 @@ int nmpc_batch_init(nmpc_batch_t* b) {
     v.head = 0;   // the interval order is rebuilt (ccs-c66x/cnmpc.c:817-828)
     // Jacobians and residuals start at zero (ccs-c66x/cnmpc.c:913-917)
     b->jacobians_zero_pending = true;
+    if (b->stage_zero_pending) {        // the kernel below writes all but z, y and the scratch
+        b->stage_zero_pending = false;
+        b->zy_zero_pending = true;
+    }
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_init_stages(v, b->stream); }));
     b->initialised = true;
     return 0;
@@ -350,6 +379,7 @@ int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_
         return fail(NMPC_E_ARG, "reference index %u beyond horizon %d", first + count - 1, b->v.N);
     TRY(use_device(b));
     sync_config(b);
+    if (b->stage_zero_pending) TRY(materialise_stage_vectors(b));
     const void* dev = nullptr;
     const bool host = !is_device_pointer(refs);
     TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(double), &dev));
@@ -392,6 +422,7 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     TRY(use_device(b));
     sync_config(b);
     TRY(materialise_jacobians(b));
+    b->zy_zero_pending = false;             // the opening step writes every z and y
     const void* dev = nullptr;
     const bool host = !is_device_pointer(measurement);
     TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(double), &dev));
@@ -439,6 +470,7 @@ int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
     TRY(use_device(b));
     sync_config(b);
     TRY(materialise_jacobians(b));
+    if (b->stage_zero_pending) TRY(materialise_stage_vectors(b));
     BatchView& v = b->v;
     const void* dev = nullptr;
     const bool host = !is_device_pointer(new_reference);
@@ -544,6 +576,7 @@ int nmpc_batch_get_stage(nmpc_batch_t* b, uint32_t instance, uint32_t k, real_t*
         return fail(NMPC_E_ARG, "nmpc_batch_get_stage: index out of range");
     TRY(use_device(b));
     TRY(materialise_jacobians(b));
+    TRY(materialise_stage_vectors(b));
     const size_t N = v.N, N1 = N + 1, ib = instance;
     const size_t s = k < N ? (size_t)((v.head + k) % v.N) : N;
     const size_t nv = k < N ? 15 : 12;

@@ -316,7 +316,15 @@ def test_piecewise_reference_loading_and_reset():
     bt0.set_reference(refs[:, :5])
     st = bt0.stages(2)
     assert st[:4, :192].any(axis=1).all() and not st[4:, :192].any()
-    # reset returns to the state after create
+    # reset returns to the state after create: everything reads as zero, also
+    # right after the next init (apart from what init itself sets)
+    bt0.reset()
+    assert not bt0.stages(3)[:, 180:].any()         # (Jacobians are cleared by init)
+    bt0.reset()
+    bt0.initialise_horizon()
+    st = bt0.stages(3)
+    assert not st[:, 238:283].any()                 # z, y
+    assert (st[:-1, 192:204] == -1e12).all()        # state bounds set by init
     bt0.reset()
     _, o2, s2, g2 = run(lambda bt: bt.set_reference(refs), bt0)
     for a, b, what in zip(o0, o2, ("controls", "status", "iterations")):
