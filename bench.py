@@ -167,7 +167,7 @@ def main():
     # control loop: prepare, feedback on a new measurement, get controls, shift the
     # horizon by one reference point (which linearises one stage).
     warm = None
-    if rank == 0 and a.warm_steps > 0:
+    if world == 1 and a.warm_steps > 0:
         dw = S.make_batch(B, N, extra_steps=a.warm_steps, seed=a.seed + rank)
         wrefs = torch.from_numpy(np.ascontiguousarray(dw["refs"][:, N + 1:])).to(dev)
         wmeas = torch.from_numpy(np.ascontiguousarray(dw["meas"][:, 1:])).to(dev)
