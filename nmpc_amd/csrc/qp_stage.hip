@@ -902,10 +902,14 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)k_line_search_tail,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_line_search_tail, dim3(grid), dim3(kTailThreads), lds, s, v, next_it);
-    hipLaunchKernelGGL(k_line_search_commit, dim3(grid), dim3(kStageThreads), stage_lds_bytes(v.N), s,
-                       v, next_it);
+    // the search kernel fills a CU with one workgroup; the two below are lighter,
+    // and warm-started batches hand over half of their instances
+    const int grid_commit = v.nb < 2048 ? v.nb : 2048;
+    const int grid_hessian = v.nb < 512 ? v.nb : 512;
+    hipLaunchKernelGGL(k_line_search_commit, dim3(grid_commit), dim3(kStageThreads),
+                       stage_lds_bytes(v.N), s, v, next_it);
     if (next_it <= kMaxIter)
-        hipLaunchKernelGGL(k_line_search_hessian, dim3(grid), dim3(kTailThreads),
+        hipLaunchKernelGGL(k_line_search_hessian, dim3(grid_hessian), dim3(kTailThreads),
                            (kTailThreads / kWave) * 2 * NX * NZ * sizeof(double), s, v, next_it);
 }
 
