@@ -95,13 +95,22 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    # Rehearsal of the multi-rank path on a box with fewer GPUs than ranks:
+    # NMPC_BENCH_REHEARSE=1 lets ranks share GPUs and gathers over gloo (RCCL
+    # refuses two ranks on one device).  Never set for a measurement.
+    rehearse = os.environ.get("NMPC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, N = a.instances, a.horizon
     # every rank draws its own instances: seed + rank
@@ -129,7 +138,7 @@ def main():
         bt.solve(meas)
         bt.get_controls_into(out_u, out_st, out_it)
         if world > 1:
-            return sharding.gather_results(out_u, out_st, out_it)
+            return sharding.gather_results(out_u, out_st, out_it, counts=[B] * world)
         return out_u, out_st, out_it
 
     for _ in range(a.warmup):

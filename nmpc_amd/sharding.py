@@ -12,19 +12,33 @@ def instance_range(total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_results(controls, status, iterations, group=None):
-    """All-gather of per-rank results along the instance axis with
-    torch.distributed (RCCL over xGMI on GPUs, gloo on CPU).  Inputs are torch
-    tensors [b_r][3] f64, [b_r] i32, [b_r] i32 with possibly unequal b_r;
-    returns the concatenation over ranks in rank order."""
+def gather_counts(count, device, group=None):
+    """Instance counts of every rank (one small all-gather and a host read)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    n = torch.tensor([controls.shape[0]], dtype=torch.int64, device=controls.device)
+    n = torch.tensor([int(count)], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    return [int(c.item()) for c in counts]
+
+
+def gather_results(controls, status, iterations, group=None, counts=None):
+    """All-gather of per-rank results along the instance axis with
+    torch.distributed (RCCL over xGMI on GPUs, gloo on CPU).  Inputs are torch
+    tensors [b_r][3] f64, [b_r] i32, [b_r] i32 with possibly unequal b_r;
+    returns the concatenation over ranks in rank order.
+
+    counts: the b_r of every rank when the caller knows them (gather_counts
+    once, or a fixed partition); without it every call exchanges them first,
+    which waits for the device."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if counts is None:
+        counts = gather_counts(controls.shape[0], controls.device, group)
     m = max(counts)
     # one packed f64 record per instance: u0 u1 u2 status iterations
     rec = torch.zeros((m, 5), dtype=torch.float64, device=controls.device)

@@ -44,6 +44,12 @@ def _worker(rank, world, port, total, N, seed, out_dir):
     u, st, it = _solve_range(lo, hi, total, N, seed)
     gu, gs, gi = sharding.gather_results(torch.from_numpy(u), torch.from_numpy(st),
                                          torch.from_numpy(it))
+    # the same with the partition known up front (no count exchange per call)
+    counts = [b - a for a, b in (sharding.instance_range(total, world, r) for r in range(world))]
+    assert counts == sharding.gather_counts(hi - lo, torch.device("cpu"))
+    ku, ks, ki = sharding.gather_results(torch.from_numpy(u), torch.from_numpy(st),
+                                         torch.from_numpy(it), counts=counts)
+    assert torch.equal(ku, gu) and torch.equal(ks, gs) and torch.equal(ki, gi)
     dist.barrier()
     if rank == 0:
         np.savez(os.path.join(out_dir, "gathered.npz"), u=gu.numpy(), st=gs.numpy(), it=gi.numpy())
