@@ -151,6 +151,18 @@ int nmpc_batch_set_wind_velocity(nmpc_batch_t *b, const real_t *wind);
 int nmpc_batch_set_reference_points(nmpc_batch_t *b, const real_t *refs,
                                     uint32_t first, uint32_t count);
 
+/* The same with the reference points made on the device from waypoints, the
+ * step the reference's harness runs on the host right before
+ * nmpc_set_reference_point (interpolate_reference,
+ * scripts/nmpc-xplane-synthetic.py:62-78): waypoints [instances][n_waypoints][17]
+ * rows (t, 16-vector reference point), sorted by t per instance; horizon
+ * position first + i gets the piecewise-linear interpolation at
+ * t0 + (first + i) dt with the attitude quaternion scaled back to unit length;
+ * past the last waypoint the last waypoint is used unchanged. */
+int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t *b, const real_t *waypoints,
+                                            uint32_t n_waypoints, real_t t0, real_t dt,
+                                            uint32_t first, uint32_t count);
+
 /* nmpc_preparation_step: no work (ccs-c66x/cnmpc.c:950-951). */
 int nmpc_batch_preparation_step(nmpc_batch_t *b);
 

@@ -96,6 +96,18 @@ class Batch:
         self._ck(self.lib.nmpc_batch_set_reference_points(self.h, a.ptr, int(first), shp[1]))
         self._keep.append(a)
 
+    def set_reference_from_waypoints(self, waypoints, t0, dt, first=0, count=None):
+        """waypoints [B][W][17] rows (t, 16-vector), sorted by t: horizon positions
+        first .. first+count-1 interpolated at t0 + position * dt on the device."""
+        shp = tuple(waypoints.shape)
+        if len(shp) != 3 or shp[0] != self.B or shp[2] != 17:
+            raise ValueError("expected [B][W][17]")
+        count = self.N + 1 - first if count is None else count
+        a = _Arg(waypoints, shp)
+        self._ck(self.lib.nmpc_batch_set_reference_from_waypoints(
+            self.h, a.ptr, shp[1], float(t0), float(dt), int(first), int(count)))
+        self._keep.append(a)
+
     # -- control loop --------------------------------------------------
     def prepare(self):
         self._ck(self.lib.nmpc_batch_preparation_step(self.h))

@@ -401,6 +401,29 @@ int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_
     return 0;
 }
 
+int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t* b, const real_t* waypoints,
+                                            uint32_t n_waypoints, real_t t0, real_t dt,
+                                            uint32_t first, uint32_t count) {
+    if (!b || !waypoints || n_waypoints == 0)
+        return fail(NMPC_E_ARG, "nmpc_batch_set_reference_from_waypoints: null or empty argument");
+    if (count == 0) return 0;
+    if ((uint64_t)first + count > (uint64_t)b->v.N + 1)
+        return fail(NMPC_E_ARG, "reference index %u beyond horizon %d", first + count - 1, b->v.N);
+    TRY(use_device(b));
+    const size_t B = (size_t)b->v.B;
+    const void* dwp = nullptr;
+    const bool host = !is_device_pointer(waypoints);
+    TRY(stage_in(b, b->in_wind, waypoints, B * n_waypoints * 17 * sizeof(double), &dwp));
+    TRY(b->scratch.reserve(B * count * 16 * sizeof(double)));
+    TRY(timed(b, NMPC_K_OTHER, [&] {
+        launch_refs_from_waypoints((int)B, (const double*)dwp, (int)n_waypoints, t0, dt, (int)first,
+                                   (int)count, (double*)b->scratch.ptr, b->stream);
+    }));
+    TRY(nmpc_batch_set_reference_points(b, (const real_t*)b->scratch.ptr, first, count));
+    if (host) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
 int nmpc_batch_preparation_step(nmpc_batch_t* b) {
     if (!b) return fail(NMPC_E_ARG, "null batch");
     return 0;

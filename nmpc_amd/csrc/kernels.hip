@@ -29,6 +29,45 @@ namespace {
 }  // namespace
 
 // ------------------------------------------------------------------------
+// Reference points from waypoints (interpolate_reference of the reference's
+// harness, scripts/nmpc-xplane-synthetic.py:62-78): waypoints [B][W][17] rows
+// (t, 16-vector), sorted by t per instance; point i of the output is the
+// piecewise-linear interpolation at t0 + (first + i) dt with the attitude
+// re-normalised (scaled by 1 / |q|, scripts/vectors.py:299-310).  Past the last
+// waypoint the last waypoint is returned as it is; before the first one the
+// first (the harness never asks for that).
+__global__ void k_refs_from_waypoints(int B, const double* __restrict__ wp, int W, double t0,
+                                      double dt, int first, int count, double* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * count) return;
+    const int b = t / count, i = t % count;
+    const double* P = wp + (size_t)b * W * 17;
+    const double at = t0 + (double)(first + i) * dt;
+    int index = 0;                              // bisect.bisect: first waypoint later than `at`
+    while (index < W && !(at < P[index * 17])) ++index;
+    double* o = out + (size_t)t * 16;
+    if (index >= W || index == 0) {
+        const double* src = P + (index >= W ? W - 1 : 0) * 17;
+        for (int j = 0; j < 16; j++) o[j] = src[1 + j];
+        return;
+    }
+    const double* a = P + (index - 1) * 17;
+    const double* c = P + index * 17;
+    const double r = (at - a[0]) / (c[0] - a[0]);
+    double pt[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) pt[j] = a[1 + j] + (c[1 + j] - a[1 + j]) * r;
+    double m = 0.;
+#pragma unroll
+    for (int j = 6; j < 10; j++) m += pt[j] * pt[j];
+    const double scale = 1.0 / sqrt(m);
+#pragma unroll
+    for (int j = 6; j < 10; j++) pt[j] = pt[j] * scale;
+#pragma unroll
+    for (int j = 0; j < 16; j++) o[j] = pt[j];
+}
+
+// ------------------------------------------------------------------------
 // refs: [B][count][16] staging buffer; point i of the range goes to horizon
 // position first + i.  Control part of position p >= 1 belongs to stage p - 1.
 __global__ void k_store_refs(BatchView v, const double* __restrict__ refs,
@@ -279,6 +318,12 @@ static inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 
 void launch_store_refs(const BatchView& v, const double* refs, int first, int count, hipStream_t s) {
     const long n = (long)v.B * count;
     hipLaunchKernelGGL(k_store_refs, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, refs, first, count);
+}
+void launch_refs_from_waypoints(int B, const double* wp, int W, double t0, double dt, int first,
+                                int count, double* out, hipStream_t s) {
+    const long n = (long)B * count;
+    hipLaunchKernelGGL(k_refs_from_waypoints, dim3(blocks_for(n, 256)), dim3(256), 0, s, B, wp, W, t0,
+                       dt, first, count, out);
 }
 void launch_init_stages(const BatchView& v, hipStream_t s) {
     const long n = (long)v.B * (v.N + 1) * NZ;

@@ -434,6 +434,66 @@ def test_relinearise_matches_resetting_every_reference_point(port_built):
         assert_same(gg[b], c.globals_(), "solver state, instance %d" % b)
 
 
+def _interpolate_like_the_harness(t, points):
+    """interpolate_reference of scripts/nmpc-xplane-synthetic.py:62-78 restated for
+    one sample time (plain Python floats): bisect on the waypoint times, linear
+    blend of all 17 entries, attitude scaled by 1 / |q| (scripts/vectors.py:299-310)."""
+    import bisect
+    import math
+    index = bisect.bisect([p[0] for p in points], t)
+    if index >= len(points):
+        return list(points[-1][1:])
+    a, b = points[index - 1], points[index]
+    delta = [y - x for x, y in zip(a, b)]
+    r = (t - a[0]) / delta[0]
+    new = [x + d * r for x, d in zip(a, delta)]
+    mag = 0.0
+    for j in range(7, 11):
+        mag += new[j] * new[j]
+    scale = 1.0 / math.sqrt(mag)
+    for j in range(7, 11):
+        new[j] = new[j] * scale
+    return new[1:]
+
+
+def test_reference_points_from_waypoints(port_built):
+    """Reference points interpolated on the device equal the harness's host
+    interpolation bit for bit, and so does everything computed from them."""
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B, dt = 40, 7, 1.0 / 50.0
+    rng = np.random.default_rng(12)
+    wp14 = S.waypoint_batch(B, rng, turn_start=(0.1, 0.6), turn_time=0.5)
+    wp = np.concatenate([wp14, np.full((B, wp14.shape[1], 3), 0.5)], axis=-1)      # controls
+    wp[:, -1, 0] = 0.9      # last leg ends inside the horizon on purpose
+    t0 = 0.013
+    host = np.array([[_interpolate_like_the_harness(t0 + i * dt, [list(p) for p in wp[b]])
+                      for i in range(N + 1)] for b in range(B)])
+    d = S.make_batch(B, N, seed=3)
+
+    def run(load):
+        bt = Batch(B, N)
+        bt.setup(**S.setup_args())
+        bt.initialise_horizon()
+        bt.set_wind_velocity(d["wind"])
+        load(bt)
+        bt.solve(host[:, 0, :13] + 0.01)
+        out = bt.get_controls()
+        st, gl = bt.stages(B - 1), bt.globals_(B - 1)
+        bt.close()
+        return out, st, gl
+
+    o_dev, s_dev, g_dev = run(lambda bt: bt.set_reference_from_waypoints(wp, t0, dt))
+    o_two, s_two, g_two = run(lambda bt: [bt.set_reference_from_waypoints(wp, t0, dt, 0, 11),
+                                          bt.set_reference_from_waypoints(wp, t0, dt, 11, N - 10)])
+    o_host, s_host, g_host = run(lambda bt: bt.set_reference(host))
+    for a, b, what in zip(o_host, o_dev, ("controls", "status", "iterations")):
+        assert_same(b, a, what)
+    assert_same(g_dev, g_host, "solver state incl. stored references")
+    assert_same(s_dev, s_host, "stage records")
+    assert_same(g_two, g_host, "solver state, waypoints loaded in two calls")
+
+
 def test_error_reporting():
     from nmpc_amd import _lib
     from nmpc_amd import synthetic as S
