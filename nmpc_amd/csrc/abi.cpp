@@ -77,7 +77,9 @@ struct Staging {        // grow-only device scratch for host-side inputs/outputs
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
-struct TimedLaunch { int kind; hipEvent_t start, stop; };
+// start may be the stop event of the launch before (owned == false): launches
+// queued back to back share the event between them.
+struct TimedLaunch { int kind; hipEvent_t start, stop; bool owned; };
 
 }  // namespace
 
@@ -107,6 +109,8 @@ struct nmpc_batch {
     bool profiling = false;
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
+    bool chain_launches = false;    // inside a sequence of launches with nothing between them
+    hipEvent_t chain_event = nullptr;
     double k_ms[NMPC_K_COUNT] = {0};
     uint64_t k_count[NMPC_K_COUNT] = {0};
 };
@@ -137,13 +141,19 @@ int timed_on(nmpc_batch* b, hipStream_t stream, int kind, F launch) {
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    TimedLaunch t{kind, nullptr, nullptr};
-    TRY(get_event(b, &t.start));
+    TimedLaunch t{kind, nullptr, nullptr, true};
+    if (b->chain_launches && b->chain_event) {
+        t.start = b->chain_event;
+        t.owned = false;
+    } else {
+        TRY(get_event(b, &t.start));
+        HIP_TRY(hipEventRecord(t.start, stream));
+    }
     TRY(get_event(b, &t.stop));
-    HIP_TRY(hipEventRecord(t.start, stream));
     launch();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(t.stop, stream));
+    b->chain_event = b->chain_launches ? t.stop : nullptr;
     b->pending.push_back(t);
     return 0;
 }
@@ -160,10 +170,11 @@ int drain_timings(nmpc_batch* b) {
         HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
         b->k_ms[t.kind] += ms;
         b->k_count[t.kind] += 1;
-        b->free_events.push_back(t.start);
+        if (t.owned) b->free_events.push_back(t.start);
         b->free_events.push_back(t.stop);
     }
     b->pending.clear();
+    b->chain_event = nullptr;
     return 0;
 }
 
@@ -294,7 +305,10 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
     if (!b) return 0;
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
-    for (auto& t : b->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto& t : b->pending) {
+        if (t.owned) (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
     for (auto ev : b->free_events) (void)hipEventDestroy(ev);
     b->in_refs.release(); b->in_meas.release(); b->in_wind.release();
     b->out_u.release(); b->out_status.release(); b->out_iters.release(); b->scratch.release();
@@ -451,6 +465,12 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(double), &dev));
     const double* dmeas = (const double*)dev;
     const BatchView& v = b->v;
+    // the launches below follow each other with nothing between them
+    struct ChainScope {
+        nmpc_batch* b;
+        explicit ChainScope(nmpc_batch* bb) : b(bb) { b->chain_launches = true; b->chain_event = nullptr; }
+        ~ChainScope() { b->chain_launches = false; b->chain_event = nullptr; }
+    } chain(b);
     TRY(timed(b, NMPC_K_QP_BEGIN, [&] { launch_qp_begin(v, dmeas, b->stream); }));
     for (int it = 1; it <= max_newton_iterations(); ++it) {
         TRY(timed(b, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, b->stream); }));
