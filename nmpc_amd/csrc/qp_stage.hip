@@ -52,6 +52,8 @@ struct StageLds {
     double* vals;   // [N+1] stage objective values by slot
     double* red;    // [8]
     int* chg;       // [N+1] active set of slot changed
+    double* terms;  // [12 N] slope terms of the fused sweep (k_newton_step), or null
+    double* prevz;  // [15] clipped point of the stage before the current chunk
 };
 
 NMPC_DEV StageLds carve(double* base, int N) {
@@ -62,11 +64,29 @@ NMPC_DEV StageLds carve(double* base, int N) {
     L.vals = base + kBufDoubles;
     L.red = L.vals + (N + 1);
     L.chg = (int*)(L.red + 8);
+    L.terms = nullptr;
+    L.prevz = nullptr;
+    return L;
+}
+
+// k_newton_step: room for the slope terms its first sweep produces on the way,
+// when the gradient fits one accumulation buffer.
+NMPC_DEV bool sweep_has_slope(int N) { return NX * N <= kBufDoubles; }
+NMPC_DEV StageLds carve_step(double* base, int N) {
+    StageLds L = carve(base, N);
+    if (sweep_has_slope(N)) {
+        L.prevz = (double*)L.chg + ((size_t)(N + 1) * sizeof(int) + 7) / 8;
+        L.terms = L.prevz + 16;
+    }
     return L;
 }
 
 inline size_t stage_lds_bytes(int N) {
     return (size_t)(kBufDoubles + (N + 1) + 8) * sizeof(double) + (size_t)(N + 1) * sizeof(int);
+}
+inline size_t step_lds_bytes(int N) {
+    const size_t base = (stage_lds_bytes(N) + 7) / 8 * 8;
+    return base + (NX * N <= kBufDoubles ? (size_t)(16 + NX * N) * sizeof(double) : 0);
 }
 
 // acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order.  The
@@ -489,22 +509,28 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
 // step to an active-set change (stage_qp_solver_clipping.c:110-126), taken from
 // the gaps of the current point; and, in the same sweep, the value trial at the
 // full step (dual_qp.c:1574-1617), which every branch of the step-length
-// selection starts with or ends at.  Returns the trial objective, *amin the
-// smallest step.
+// selection starts with or ends at, together with the rows of the dual gradient
+// at that trial point (dual_qp.c:574-597): they give the slope of the first
+// bisection trial and, if the full step is committed, the gradient of the next
+// Newton set-up, and they read each Jacobian block while the direction pass
+// has just fetched it.  Stages are visited in horizon order, kStageChunk at a
+// time; the rows of a stage are done once its successor's point is known.
+// Returns the trial objective; *aminOut the smallest step; with L.terms:
+// *slopeOut the slope at the full step, and grad is written when keepGrad.
 NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I, const StageLds& L,
-                                               double* aminOut) {
+                                               bool keepGrad, double* aminOut, double* slopeOut) {
     const int tid = threadIdx.x, N = v.N;
-    const int eEnd = NZ * N + NX;
     const double a = 1.;
+    const bool rows = L.terms != nullptr;
     double amin = kInfty;
     for (int c0 = 0; c0 <= N; c0 += kStageChunk) {
         const int c1 = (c0 + kStageChunk <= N + 1) ? c0 + kStageChunk : N + 1;
-        const int e0 = c0 * NZ;
-        const int e1 = (c1 * NZ < eEnd) ? c1 * NZ : eEnd;
-        for (int e = e0 + tid; e < e1; e += kStageThreads) {
-            const int s = e / NZ, j = e - s * NZ, k = slot_position(v, s);
+        for (int idx = tid; idx < (c1 - c0) * NZ; idx += kStageThreads) {
+            const int kk = idx / NZ, j = idx - kk * NZ, k = c0 + kk;
+            if (k == N && j >= NX) continue;
+            const int s = stage_slot(v, k), e = s * NZ + j;
             double qs;
-            if (s < N) {
+            if (k < N) {
                 const double* Cc = I.C + (size_t)s * (NX * NZ) + j;
                 const double* l1 = I.dl + k * NX;
                 qs = 0.;
@@ -515,7 +541,7 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
             }
             if (k > 0 && j < NX) qs -= I.dl[(k - 1) * NX + j];
             I.qStep[e] = qs;
-            const double d = qs / (s < N ? v.H[j] : v.Ht[j]);
+            const double d = qs / (k < N ? v.H[j] : v.Ht[j]);
             const double dzv = -d;
             I.dz[e] = dzv;
             const double r0 = dzv / I.y[2 * e];
@@ -529,33 +555,57 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
             I.y[2 * e] = y0;
             I.y[2 * e + 1] = y1;
             I.z[e] = zc;
-            L.z[e - e0] = zc;
-            L.q[e - e0] = I.q[e] + a * qs;
+            L.z[idx] = zc;
+            L.q[idx] = I.q[e] + a * qs;
         }
         __syncthreads();
-        for (int s = c0 + tid; s < c1; s += kStageThreads) {
+        for (int k = c0 + tid; k < c1; k += kStageThreads) {
+            const int s = stage_slot(v, k);
             double ps = 0.;
-            if (s < N) {
-                const double* l1 = I.dl + slot_position(v, s) * NX;
+            if (k < N) {
+                const double* l1 = I.dl + k * NX;
 #pragma unroll
                 for (int i = 0; i < NX; i++) ps += l1[i] * I.c[s * NX + i];
             }
             I.pStep[s] = ps;
-            const int nV = s < N ? NZ : NX;
-            const double* H = s < N ? v.H : v.Ht;
+            const int nV = k < N ? NZ : NX;
+            const double* H = k < N ? v.H : v.Ht;
             const double pt = I.p[s] + a * ps;
-            L.vals[s] = stage_value(H, L.z + (s - c0) * NZ, L.q + (s - c0) * NZ, pt, nV);
+            L.vals[k] = stage_value(H, L.z + (k - c0) * NZ, L.q + (k - c0) * NZ, pt, nV);
+        }
+        if (rows) {
+            // gradient rows of the stages whose successor is in LDS now
+            const int kFirst = c0 > 0 ? c0 - 1 : 0;
+            for (int rr = tid; rr < (c1 - 1 - kFirst) * NX; rr += kStageThreads) {
+                const int kk = rr / NX, i = rr - kk * NX, k = kFirst + kk;
+                const int s = stage_slot(v, k);
+                const double* Crow = I.C + (size_t)s * (NX * NZ) + i * NZ;
+                const double* zk = (k >= c0) ? L.z + (k - c0) * NZ : L.prevz;
+                double g = 0.;
+#pragma unroll
+                for (int j = 0; j < NZ; j++) g += Crow[j] * zk[j];
+                g += I.c[s * NX + i];
+                g -= L.z[(k + 1 - c0) * NZ + i];
+                if (keepGrad) I.grad[k * NX + i] = g;
+                L.terms[k * NX + i] = g * I.dl[k * NX + i];
+            }
         }
         __syncthreads();
+        if (rows && c1 <= N) {                  // the last stage of this chunk, for the next one
+            if (tid < NZ) L.prevz[tid] = L.z[(c1 - 1 - c0) * NZ + tid];
+            __syncthreads();
+        }
     }
-    if (tid < kWave) {
-        double acc = accumulate_in_order(0., L.vals + v.head, N - v.head);
-        acc = accumulate_in_order(acc, L.vals, v.head);
-        acc += L.vals[N];
-        if (tid == 0) L.red[0] = acc;
+    // objective (stage values in horizon order) and slope, side by side
+    if (tid < 2) {
+        const double acc = accumulate_in_order(0., (tid == 1 && rows) ? L.terms : L.vals,
+                                               (tid == 1 && rows) ? NX * N : N + 1);
+        L.red[tid] = acc;
     }
     __syncthreads();
     const double obj = L.red[0];
+    *slopeOut = L.red[1];
+    __syncthreads();                            // block_min reuses red[1..]
     *aminOut = block_min(amin, L);
     return obj;
 }
@@ -628,7 +678,7 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int nextIt) {
     extern __shared__ double lds_raw[];
-    const StageLds L = carve(lds_raw, v.N);
+    const StageLds L = carve_step(lds_raw, v.N);
     const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
     if (I.sc->status != ST_RUNNING) return;
@@ -638,11 +688,14 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 
     for (int s = tid; s <= N; s += kStageThreads) L.chg[s] = 0;
 
-    double alphaMinAS;
+    double alphaMinAS, fullStepSlope;
+    const bool keepGrad = nextIt <= kMaxIter;   // the last iteration leaves the gradient record alone
+    const bool haveSlope = L.terms != nullptr;
     // z and y hold the value trial at step length zAlpha, whose objective is objKept
-    double objKept = directions_and_full_step_trial(v, I, L, &alphaMinAS);
+    double objKept = directions_and_full_step_trial(v, I, L, keepGrad, &alphaMinAS, &fullStepSlope);
     double zAlpha = 1.;
-    double gradAlpha = __builtin_nan("");   // step length whose gradient grad holds, if any
+    // step length whose gradient grad holds, if any
+    double gradAlpha = (haveSlope && keepGrad) ? 1. : __builtin_nan("");
 
     double alpha;
     int lsIter = 0;
@@ -681,6 +734,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
         // which evaluates them faster than this kernel's resources allow.  A trial
         // at the step length z already holds needs no new trial point.
         auto slope_at = [&](double at) {
+            if (haveSlope && at == 1.) return fullStepSlope;    // the first sweep made it
             if (at == zAlpha) {
                 // the gradient at z is what the next Newton set-up starts from if this
                 // step length is committed: keep it (the last iteration has no set-up
@@ -890,7 +944,7 @@ void launch_qp_begin(const BatchView& v, const double* meas, hipStream_t s) {
     hipLaunchKernelGGL(k_qp_begin, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
 }
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
-    hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, next_it);
+    hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), step_lds_bytes(v.N), s, v, next_it);
 }
 bool line_search_tail_enabled(const BatchView& v) {
     return v.tailList != nullptr && v.N <= kTailMaxHorizon;
