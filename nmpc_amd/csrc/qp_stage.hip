@@ -53,6 +53,7 @@ struct StageLds {
     double* red;    // [8]
     int* chg;       // [N+1] active set of slot changed
     double* terms;  // [12 N] slope terms of the fused sweep (k_newton_step), or null
+    double* sqr;    // [12 N] squared gradient rows of the same sweep
     double* prevz;  // [15] clipped point of the stage before the current chunk
 };
 
@@ -65,6 +66,7 @@ NMPC_DEV StageLds carve(double* base, int N) {
     L.red = L.vals + (N + 1);
     L.chg = (int*)(L.red + 8);
     L.terms = nullptr;
+    L.sqr = nullptr;
     L.prevz = nullptr;
     return L;
 }
@@ -77,6 +79,7 @@ NMPC_DEV StageLds carve_step(double* base, int N) {
     if (sweep_has_slope(N)) {
         L.prevz = (double*)L.chg + ((size_t)(N + 1) * sizeof(int) + 7) / 8;
         L.terms = L.prevz + 16;
+        L.sqr = L.terms + NX * N;
     }
     return L;
 }
@@ -86,7 +89,7 @@ inline size_t stage_lds_bytes(int N) {
 }
 inline size_t step_lds_bytes(int N) {
     const size_t base = (stage_lds_bytes(N) + 7) / 8 * 8;
-    return base + (NX * N <= kBufDoubles ? (size_t)(16 + NX * N) * sizeof(double) : 0);
+    return base + (NX * N <= kBufDoubles ? (size_t)(16 + 2 * NX * N) * sizeof(double) : 0);
 }
 
 // acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order.  The
@@ -265,10 +268,12 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
 // step stored it).
 // Returns false when the gradient norm passes the convergence test.
 NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& L, int it,
-                             bool gradKept) {
+                             bool gradKept, const double* normKept = nullptr) {
     const int tid = threadIdx.x, N = v.N;
     double nn;
-    if (gradKept) {
+    if (gradKept && normKept) {
+        nn = *normKept;
+    } else if (gradKept) {
         nn = block_ordered_sum(NX * N, L, [&](int r) {
             const double g = I.grad[r];
             return g * g;
@@ -383,8 +388,8 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
 }
 
 NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it,
-                           bool gradKept = false) {
-    if (setup_gradient(v, I, L, it, gradKept))
+                           bool gradKept = false, const double* normKept = nullptr) {
+    if (setup_gradient(v, I, L, it, gradKept, normKept))
         assemble_hessian<kStageThreads / kWave>(v, I, L.buf);
 }
 
@@ -477,7 +482,8 @@ NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, double a, con
 // objective of the value trial that z and y still hold, or is null.
 NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, double alpha,
                           int lsIter, int nextIt, const double* keptObjective = nullptr,
-                          bool gradKept = false, bool withHessian = true) {
+                          bool gradKept = false, bool withHessian = true,
+                          const double* normKept = nullptr) {
     const int tid = threadIdx.x, n = NX * v.N;
     for (int r = tid; r < n; r += kStageThreads) {
         double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
@@ -499,7 +505,7 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
     }
     if (nextIt <= kMaxIter) {
         __syncthreads();
-        if (withHessian) newton_setup(v, I, L, nextIt, gradKept && keptObjective);
+        if (withHessian) newton_setup(v, I, L, nextIt, gradKept && keptObjective, normKept);
         else setup_gradient(v, I, L, nextIt, gradKept && keptObjective);
     }
 }
@@ -518,7 +524,8 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
 // Returns the trial objective; *aminOut the smallest step; with L.terms:
 // *slopeOut the slope at the full step, and grad is written when keepGrad.
 NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I, const StageLds& L,
-                                               bool keepGrad, double* aminOut, double* slopeOut) {
+                                               bool keepGrad, double* aminOut, double* slopeOut,
+                                               double* normOut) {
     const int tid = threadIdx.x, N = v.N;
     const double a = 1.;
     const bool rows = L.terms != nullptr;
@@ -588,6 +595,7 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
                 g -= L.z[(k + 1 - c0) * NZ + i];
                 if (keepGrad) I.grad[k * NX + i] = g;
                 L.terms[k * NX + i] = g * I.dl[k * NX + i];
+                L.sqr[k * NX + i] = g * g;
             }
         }
         __syncthreads();
@@ -596,15 +604,16 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
             __syncthreads();
         }
     }
-    // objective (stage values in horizon order) and slope, side by side
-    if (tid < 2) {
-        const double acc = accumulate_in_order(0., (tid == 1 && rows) ? L.terms : L.vals,
-                                               (tid == 1 && rows) ? NX * N : N + 1);
-        L.red[tid] = acc;
+    // objective (stage values in horizon order), slope and squared gradient norm,
+    // side by side
+    if (tid < 3) {
+        const double* src = (tid == 0 || !rows) ? L.vals : (tid == 1 ? L.terms : L.sqr);
+        L.red[tid] = accumulate_in_order(0., src, (tid == 0 || !rows) ? N + 1 : NX * N);
     }
     __syncthreads();
     const double obj = L.red[0];
     *slopeOut = L.red[1];
+    *normOut = L.red[2];
     __syncthreads();                            // block_min reuses red[1..]
     *aminOut = block_min(amin, L);
     return obj;
@@ -688,14 +697,16 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 
     for (int s = tid; s <= N; s += kStageThreads) L.chg[s] = 0;
 
-    double alphaMinAS, fullStepSlope;
+    double alphaMinAS, fullStepSlope, fullStepNorm2;
     const bool keepGrad = nextIt <= kMaxIter;   // the last iteration leaves the gradient record alone
     const bool haveSlope = L.terms != nullptr;
     // z and y hold the value trial at step length zAlpha, whose objective is objKept
-    double objKept = directions_and_full_step_trial(v, I, L, keepGrad, &alphaMinAS, &fullStepSlope);
+    double objKept = directions_and_full_step_trial(v, I, L, keepGrad, &alphaMinAS, &fullStepSlope,
+                                                    &fullStepNorm2);
     double zAlpha = 1.;
     // step length whose gradient grad holds, if any
     double gradAlpha = (haveSlope && keepGrad) ? 1. : __builtin_nan("");
+    bool gradFromSweep = haveSlope && keepGrad;     // false once a slope trial rewrites grad
 
     double alpha;
     int lsIter = 0;
@@ -740,7 +751,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
                 // step length is committed: keep it (the last iteration has no set-up
                 // and leaves the gradient record alone)
                 const bool keep = nextIt <= kMaxIter;
-                if (keep) gradAlpha = at;
+                if (keep) { gradAlpha = at; gradFromSweep = false; }
                 return block_ordered_sum(n, L, [&](int r) {
                     const double g = gradient_row(v, I, I.z, r);
                     if (keep) I.grad[r] = g;
@@ -778,8 +789,10 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
         alpha = bs.alpha;
         lsIter = bs.it;
     }
+    // grad can only be the first sweep's here when it belongs to the full step
     commit_step(v, I, L, alpha, lsIter, nextIt, (alpha == zAlpha) ? &objKept : nullptr,
-                alpha == gradAlpha);
+                alpha == gradAlpha, true,
+                (haveSlope && gradFromSweep && alpha == 1.) ? &fullStepNorm2 : nullptr);
 }
 
 // ------------------------------------------------------------------------
