@@ -165,9 +165,12 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
 
     // Block rows are fetched one iteration ahead.  Lanes that will factorise a
     // block start from the Newton Hessian, the others read their factor back.
-    double nL[NX], nLs[NX], ng, nd;
-    {
-        const bool f = active && (N - 1 <= start);
+    // Groups whose results are dropped fetch nothing and work on zeros.
+    double nL[NX], nLs[NX], ng = 0., nd = 1.;
+#pragma unroll
+    for (int l = 0; l < NX; l++) { nL[l] = 0.; nLs[l] = 0.; }
+    if (active) {
+        const bool f = N - 1 <= start;
         const double* src = f ? I.hess : I.chol;
 #pragma unroll
         for (int l = 0; l < NX; l++) {
@@ -186,10 +189,10 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         for (int l = 0; l < NX; l++) { L[l] = nL[l]; Ls[l] = nLs[l]; }
         const double g = ng;
         double dd = nd;                                // chol(k,0,t,t) unless refactorised below
-        if (k > 0) {
+        if (k > 0 && active) {
             // a failure in this block is not known yet; a group that fails stops
             // using what it fetched, so the guess "still factorising" is harmless
-            const bool f = active && status == ST_OK && (k - 1 <= start);
+            const bool f = status == ST_OK && (k - 1 <= start);
             const double* src = f ? I.hess : I.chol;
 #pragma unroll
             for (int l = 0; l < NX; l++) {
@@ -241,18 +244,22 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 #pragma unroll
     for (int j = 0; j < NX; j++) { xk[j] = 0.; xo[j] = 0.; }
     double norm2 = 0.;
-    double nLd[NX], nLr[NX], nsum, nd;
+    double nLd[NX], nLr[NX], nsum = 0., nd = 1.;
 #pragma unroll
-    for (int j = 0; j < NX; j++) { nLd[j] = HS(I.chol, 0, 0, tc, j); nLr[j] = HS(I.chol, 0, -1, tc, j); }
-    nsum = I.dl[tc];
-    nd = HS(I.chol, 0, 0, tc, tc);
+    for (int j = 0; j < NX; j++) { nLd[j] = 0.; nLr[j] = 0.; }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) { nLd[j] = HS(I.chol, 0, 0, tc, j); nLr[j] = HS(I.chol, 0, -1, tc, j); }
+        nsum = I.dl[tc];
+        nd = HS(I.chol, 0, 0, tc, tc);
+    }
     for (int k = 0; k < N; ++k) {
         double Ld[NX], Lr[NX];
 #pragma unroll
         for (int j = 0; j < NX; j++) { Ld[j] = nLd[j]; Lr[j] = nLr[j]; }
         double sum = nsum;
         const double dd = nd;
-        if (k + 1 < N) {
+        if (k + 1 < N && live) {
 #pragma unroll
             for (int j = 0; j < NX; j++) {
                 nLd[j] = HS(I.chol, k + 1, 0, tc, j);
