@@ -29,9 +29,11 @@ namespace {
 // have nothing to do are computed and dropped.
 constexpr int kGroupsPerWave = 4;
 
+using Seq12 = std::make_integer_sequence<int, NX>;
+
 template <int SRC>
 NMPC_DEV double row_bcast(double x) {   // value held by lane SRC of this lane's group
-    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, true);
 }
 
 NMPC_DEV double group_min(double x) {
@@ -49,23 +51,81 @@ NMPC_DEV double group_min(double x) {
 // chol(k,-1) and chol(k+1,-1); on entry L[JJ] and Ls[JJ] still hold the Newton
 // Hessian entries they are computed from.  Lanes with doit == false keep
 // their L[JJ], Ls[JJ].
+//
+// The reference takes the products away from the pivot one after the other,
+// the one with the row just finished first, so a column is one chain of up to
+// 23 dependent subtractions.  Only that chain has to be serial: all products
+// of column JJ but the first are known while column JJ+1 is still summing, and
+// are made there, between its subtractions (Products q), each pinned in
+// place so that the compiler keeps the interleaving.
+struct Products {
+    double a[NX];   // L[l]  * chol(k,0,l,JJ),     l >= JJ+2
+    double b[NX];   // Ls[l] * chol(k,0,l,JJ),     l >= JJ+2
+    double c[NX];   // Ln[l] * chol(k+1,-1,l,JJ),  all l
+};
+
+#define NMPC_PIN(x) asm volatile("" : "+v"(x))
+
+// Item I of the products of column JJ: the twelve c first, then the (a, b) pairs.
+template <int JJ, int I>
+NMPC_DEV void make_product(Products& q, const double (&L)[NX], const double (&Ls)[NX],
+                           const double (&Ln)[NX]) {
+    if constexpr (JJ >= 0 && I < NX) {
+        q.c[I] = Ln[I] * row_bcast<JJ>(Ln[I]);
+        NMPC_PIN(q.c[I]);
+    } else if constexpr (JJ >= 0 && JJ + 2 + (I - NX) < NX) {
+        constexpr int l = JJ + 2 + (I - NX);
+        const double ljj = row_bcast<JJ>(L[l]);
+        q.a[l] = L[l] * ljj;
+        q.b[l] = Ls[l] * ljj;
+        NMPC_PIN(q.a[l]);
+        NMPC_PIN(q.b[l]);
+    }
+}
+
+template <int JJ, int... I>
+NMPC_DEV void make_products(Products& q, const double (&L)[NX], const double (&Ls)[NX],
+                            const double (&Ln)[NX], std::integer_sequence<int, I...>) {
+    (make_product<JJ, I>(q, L, Ls, Ln), ...);
+}
+
+// Step S of column JJ's chain, followed by item S of the next column's products.
+template <int JJ, int S>
+NMPC_DEV void chain_step(double& sum, double& sub, const Products& p, Products& q,
+                         const double (&L)[NX], const double (&Ls)[NX], const double (&Ln)[NX]) {
+    constexpr int nAB = JJ + 2 < NX ? NX - 2 - JJ : 0;
+    if constexpr (S < nAB) {
+        sum -= p.a[JJ + 2 + S];
+        sub -= p.b[JJ + 2 + S];
+        NMPC_PIN(sub);
+    } else {
+        sum -= p.c[S - nAB];
+    }
+    NMPC_PIN(sum);
+    make_product<JJ - 1, S>(q, L, Ls, Ln);
+}
+
+template <int JJ, int... S>
+NMPC_DEV void chain_steps(double& sum, double& sub, const Products& p, Products& q,
+                          const double (&L)[NX], const double (&Ls)[NX], const double (&Ln)[NX],
+                          std::integer_sequence<int, S...>) {
+    (chain_step<JJ, S>(sum, sub, p, q, L, Ls, Ln), ...);
+}
+
 template <int JJ>
 NMPC_DEV void factor_column(double (&L)[NX], double (&Ls)[NX], const double (&Ln)[NX],
-                            bool below, bool doit, int t, int& failCol, double& diag) {
+                            Products& p, bool doit, int t, int& failCol, double& diag) {
+    constexpr int nAB = JJ + 2 < NX ? NX - 2 - JJ : 0;
     double sum = L[JJ], sub = Ls[JJ];
-#pragma unroll
-    for (int l = JJ + 1; l < NX; ++l) {
-        const double ljj = row_bcast<JJ>(L[l]);         // chol(k,0,l,JJ)
-        sum -= L[l] * ljj;
-        sub -= Ls[l] * ljj;
+    if constexpr (JJ + 1 < NX) {
+        const double ljj = row_bcast<JJ>(L[JJ + 1]);    // chol(k,0,JJ+1,JJ), just finished
+        sum -= L[JJ + 1] * ljj;
+        sub -= Ls[JJ + 1] * ljj;
     }
-    if (below) {
-#pragma unroll
-        for (int l = 0; l < NX; ++l) {
-            const double njj = row_bcast<JJ>(Ln[l]);    // chol(k+1,-1,l,JJ)
-            sum -= Ln[l] * njj;
-        }
-    }
+    Products q;
+    chain_steps<JJ>(sum, sub, p, q, L, Ls, Ln, std::make_integer_sequence<int, nAB + NX>{});
+    // the next column has one product more than this chain has steps
+    make_product<JJ - 1, nAB + NX>(q, L, Ls, Ln);
     const double piv = row_bcast<JJ>(sum);
     if (doit && failCol < 0 && piv < 1.e2 * kEqTol) failCol = JJ;
     const double d = sqrt(piv);
@@ -74,13 +134,18 @@ NMPC_DEV void factor_column(double (&L)[NX], double (&Ls)[NX], const double (&Ln
     const double ls = sub / d;
     L[JJ] = doit ? ld : L[JJ];
     Ls[JJ] = doit ? ls : Ls[JJ];
+    if constexpr (JJ > 0) p = q;
 }
 
 template <int... JJ>
 NMPC_DEV void factor_columns(double (&L)[NX], double (&Ls)[NX], const double (&Ln)[NX],
-                             bool below, bool doit, int t, int& failCol, double& diag,
+                             bool doit, int t, int& failCol, double& diag,
                              std::integer_sequence<int, JJ...>) {
-    (factor_column<NX - 1 - JJ>(L, Ls, Ln, below, doit, t, failCol, diag), ...);
+    // The last block row has nothing below it: Ln is zero there, and taking
+    // +0 away leaves a sum as it is, so its c terms need no branch around them.
+    Products p;
+    make_products<NX - 1>(p, L, Ls, Ln, Seq12{});
+    (factor_column<NX - 1 - JJ>(L, Ls, Ln, p, doit, t, failCol, diag), ...);
 }
 
 // The substitutions divide by pivots that are known long before the numerator
@@ -106,14 +171,12 @@ NMPC_DEV double divide(double n, const Pivot& p) {
 // Row R of the bottom-up substitution L' x = g for block k (dual_qp.c:1003-1026).
 template <bool FAST, int R>
 NMPC_DEV void backsolve_row(double (&xk)[NX], double& mine, const double (&L)[NX],
-                            const double (&pn)[NX], double g, const Pivot& dd, bool below, int t) {
+                            const double (&pn)[NX], double g, const Pivot& dd, int t) {
     double sum = g;
 #pragma unroll
     for (int j = R + 1; j < NX; ++j) sum -= L[j] * xk[j];
-    if (below) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) sum -= pn[j];
-    }
+    for (int j = 0; j < NX; ++j) sum -= pn[j];          // +0 in the last block row
     const double x = divide<FAST>(sum, dd);
     xk[R] = row_bcast<R>(x);
     mine = (t == R) ? x : mine;
@@ -121,9 +184,9 @@ NMPC_DEV void backsolve_row(double (&xk)[NX], double& mine, const double (&L)[NX
 
 template <bool FAST, int... R>
 NMPC_DEV void backsolve_rows(double (&xk)[NX], double& mine, const double (&L)[NX],
-                             const double (&pn)[NX], double g, const Pivot& dd, bool below, int t,
+                             const double (&pn)[NX], double g, const Pivot& dd, int t,
                              std::integer_sequence<int, R...>) {
-    (backsolve_row<FAST, NX - 1 - R>(xk, mine, L, pn, g, dd, below, t), ...);
+    (backsolve_row<FAST, NX - 1 - R>(xk, mine, L, pn, g, dd, t), ...);
 }
 
 // Column J of the top-down substitution L x = y for block k
@@ -145,8 +208,6 @@ NMPC_DEV void forward_columns(double (&xk)[NX], double& mine, double& sum,
                               std::integer_sequence<int, J...>) {
     (forward_column<FAST, J>(xk, mine, sum, Ld, dd, t), ...);
 }
-
-using Seq12 = std::make_integer_sequence<int, NX>;
 
 // One sweep from block N-1 down to 0: blocks k <= start of an `active` group
 // are factorised (dual_qp.c:817-908), the others read their factor back; each
@@ -182,7 +243,6 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
     }
 
     for (int k = N - 1; k >= 0; --k) {
-        const bool below = k < N - 1;
         const bool factorThis = active && status == ST_OK && k <= start;
         double L[NX], Ls[NX];
 #pragma unroll
@@ -204,7 +264,7 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         }
         if (__any(factorThis)) {
             int failCol = -1;
-            factor_columns(L, Ls, Ln, below, factorThis, t, failCol, dd, Seq12{});
+            factor_columns(L, Ls, Ln, factorThis, t, failCol, dd, Seq12{});
             if (factorThis && col) {
 #pragma unroll
                 for (int l = 0; l < NX; l++)
@@ -222,9 +282,9 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         double mine = 0.;
         const Pivot pv{dd, 1.0 / dd};
         if (__any(plain_division_needed(dd)))
-            backsolve_rows<false>(xk, mine, L, pn, g, pv, below, t, Seq12{});
+            backsolve_rows<false>(xk, mine, L, pn, g, pv, t, Seq12{});
         else
-            backsolve_rows<true>(xk, mine, L, pn, g, pv, below, t, Seq12{});
+            backsolve_rows<true>(xk, mine, L, pn, g, pv, t, Seq12{});
         if (active && status == ST_OK && col) I.dl[k * NX + t] = mine;
 #pragma unroll
         for (int j = 0; j < NX; j++) { pn[j] = Ls[j] * xk[j]; Ln[j] = Ls[j]; }
