@@ -45,12 +45,58 @@ NMPC_DEV double group_min(double x) {
     return x;
 }
 
+// The substitutions divide by pivots that are known long before the numerator
+// is.  With y = RN(1 / d) prepared ahead, the correctly rounded quotient takes
+// three dependent instructions instead of about ten (Markstein's sequence:
+// q0 = RN(n y) is a faithful quotient, the residual is exact in an FMA, and the
+// corrected value rounds to RN(n / d)).  The faithfulness argument excludes
+// divisors whose significand is all ones; blocks that hold one use plain
+// division.  Checked against n / d on 2.6e10 random and adversarial operand
+// pairs on gfx950 (tools/micro_div.hip): no difference.
+struct Pivot { double d, y; };
+NMPC_DEV bool plain_division_needed(double d) {
+    return (__double_as_longlong(d) & 0xfffffffffffffLL) == 0xfffffffffffffLL;
+}
+template <bool FAST>
+NMPC_DEV double divide(double n, const Pivot& p) {
+    if (!FAST) return n / p.d;
+    const double q0 = n * p.y;
+    const double r = __builtin_fma(-p.d, q0, n);
+    return __builtin_fma(r, p.y, q0);
+}
+
+// d = sqrt(x) and y = RN(1 / d) for a pivot x.  The root is the compiler's own
+// expansion of sqrt (v_rsq_f64, one Goldschmidt step, two corrections) without
+// the rescaling it applies to x < 2^-767, far below the smallest pivot the
+// factorisation accepts.  That iteration carries h ~ 1 / (2 d) along; refined once more
+// beside the corrections of the root, it starts one Newton step and Markstein's
+// correction, which give the correctly rounded reciprocal of every d whose
+// significand is not all ones.  Checked against sqrt, 1 / d and n / d on 2.6e10
+// random and adversarial operands on gfx950 (tools/micro_sqrt.hip): no difference.
+NMPC_DEV Pivot root_and_reciprocal(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = r * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double e2 = __builtin_fma(-h, g, 0.5);
+    const double h2 = __builtin_fma(h, e2, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d1, h, g);
+    const double y0 = h2 + h2;
+    const double e0 = __builtin_fma(-g, y0, 1.0);
+    const double y1 = __builtin_fma(e0, y0, y0);
+    const double e1 = __builtin_fma(-g, y1, 1.0);
+    return {g, __builtin_fma(e1, y1, y1)};
+}
+
 // Column JJ of block row k of the reverse Cholesky (dual_qp.c:832-903): pivot,
 // the entries left of it in the diagonal block and the whole row of the
 // sub-diagonal block.  L / Ls / Ln hold this lane's column of chol(k,0),
 // chol(k,-1) and chol(k+1,-1); on entry L[JJ] and Ls[JJ] still hold the Newton
-// Hessian entries they are computed from.  Lanes with doit == false keep
-// their L[JJ], Ls[JJ].
+// Hessian entries they are computed from.
 //
 // The reference takes the products away from the pivot one after the other,
 // the one with the row just finished first, so a column is one chain of up to
@@ -112,9 +158,13 @@ NMPC_DEV void chain_steps(double& sum, double& sub, const Products& p, Products&
     (chain_step<JJ, S>(sum, sub, p, q, L, Ls, Ln), ...);
 }
 
-template <int JJ>
+// FAST takes root and reciprocal together and leaves in `ones` the largest low
+// word of a root: a root whose significand is all ones (the one case the
+// reciprocal is not good for) shows there as 0xffffffff, and the caller then
+// repeats the block with FAST off.
+template <bool FAST, int JJ>
 NMPC_DEV void factor_column(double (&L)[NX], double (&Ls)[NX], const double (&Ln)[NX],
-                            Products& p, bool doit, int t, int& failCol, double& diag) {
+                            Products& p, int t, int& failCol, double& diag, uint32_t& ones) {
     constexpr int nAB = JJ + 2 < NX ? NX - 2 - JJ : 0;
     double sum = L[JJ], sub = Ls[JJ];
     if constexpr (JJ + 1 < NX) {
@@ -127,45 +177,35 @@ NMPC_DEV void factor_column(double (&L)[NX], double (&Ls)[NX], const double (&Ln
     // the next column has one product more than this chain has steps
     make_product<JJ - 1, nAB + NX>(q, L, Ls, Ln);
     const double piv = row_bcast<JJ>(sum);
-    if (doit && failCol < 0 && piv < 1.e2 * kEqTol) failCol = JJ;
-    const double d = sqrt(piv);
-    diag = (doit && t == JJ) ? d : diag;
-    const double ld = (t == JJ) ? d : sum / d;
-    const double ls = sub / d;
-    L[JJ] = doit ? ld : L[JJ];
-    Ls[JJ] = doit ? ls : Ls[JJ];
+    if (failCol < 0 && piv < 1.e2 * kEqTol) failCol = JJ;
+    double d, ld, ls;
+    if constexpr (FAST) {
+        const Pivot pv = root_and_reciprocal(piv);
+        d = pv.d;
+        ld = divide<true>(sum, pv);
+        ls = divide<true>(sub, pv);
+        const uint32_t lo = (uint32_t)__double_as_longlong(d);
+        ones = lo > ones ? lo : ones;
+    } else {
+        d = sqrt(piv);
+        ld = sum / d;
+        ls = sub / d;
+    }
+    diag = (t == JJ) ? d : diag;
+    L[JJ] = (t == JJ) ? d : ld;
+    Ls[JJ] = ls;
     if constexpr (JJ > 0) p = q;
 }
 
-template <int... JJ>
+template <bool FAST, int... JJ>
 NMPC_DEV void factor_columns(double (&L)[NX], double (&Ls)[NX], const double (&Ln)[NX],
-                             bool doit, int t, int& failCol, double& diag,
+                             int t, int& failCol, double& diag, uint32_t& ones,
                              std::integer_sequence<int, JJ...>) {
     // The last block row has nothing below it: Ln is zero there, and taking
     // +0 away leaves a sum as it is, so its c terms need no branch around them.
     Products p;
     make_products<NX - 1>(p, L, Ls, Ln, Seq12{});
-    (factor_column<NX - 1 - JJ>(L, Ls, Ln, p, doit, t, failCol, diag), ...);
-}
-
-// The substitutions divide by pivots that are known long before the numerator
-// is.  With y = RN(1 / d) prepared ahead, the correctly rounded quotient takes
-// three dependent instructions instead of about ten (Markstein's sequence:
-// q0 = RN(n y) is a faithful quotient, the residual is exact in an FMA, and the
-// corrected value rounds to RN(n / d)).  The faithfulness argument excludes
-// divisors whose significand is all ones; blocks that hold one use plain
-// division.  Checked against n / d on 2.6e10 random and adversarial operand
-// pairs on gfx950 (tools/micro_div.hip): no difference.
-struct Pivot { double d, y; };
-NMPC_DEV bool plain_division_needed(double d) {
-    return (__double_as_longlong(d) & 0xfffffffffffffLL) == 0xfffffffffffffLL;
-}
-template <bool FAST>
-NMPC_DEV double divide(double n, const Pivot& p) {
-    if (!FAST) return n / p.d;
-    const double q0 = n * p.y;
-    const double r = __builtin_fma(-p.d, q0, n);
-    return __builtin_fma(r, p.y, q0);
+    (factor_column<FAST, NX - 1 - JJ>(L, Ls, Ln, p, t, failCol, diag, ones), ...);
 }
 
 // Row R of the bottom-up substitution L' x = g for block k (dual_qp.c:1003-1026).
@@ -224,15 +264,19 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
 #pragma unroll
     for (int j = 0; j < NX; j++) { Ln[j] = 0.; pn[j] = 0.; xk[j] = 0.; }
 
-    // Block rows are fetched one iteration ahead.  Lanes that will factorise a
-    // block start from the Newton Hessian, the others read their factor back.
+    // Block rows are fetched one iteration ahead.  When any group of the
+    // wavefront factorises a block, every group does, starting from the Newton
+    // Hessian: a block above a group's `start` has the same Hessian and the same
+    // factor below it as when it was last factorised (that is why the reference
+    // skips it), so the result is the factor it would have read back, and the
+    // columns need no per-lane choice between a computed and a fetched value.
     // Groups whose results are dropped fetch nothing and work on zeros.
     double nL[NX], nLs[NX], ng = 0., nd = 1.;
 #pragma unroll
     for (int l = 0; l < NX; l++) { nL[l] = 0.; nLs[l] = 0.; }
+    bool nextFromHess = __any(active && N - 1 <= start);
     if (active) {
-        const bool f = N - 1 <= start;
-        const double* src = f ? I.hess : I.chol;
+        const double* src = nextFromHess ? I.hess : I.chol;
 #pragma unroll
         for (int l = 0; l < NX; l++) {
             nL[l] = HS(src, N - 1, 0, l, tc);
@@ -243,28 +287,46 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
     }
 
     for (int k = N - 1; k >= 0; --k) {
+        const bool fromHess = nextFromHess;
         const bool factorThis = active && status == ST_OK && k <= start;
         double L[NX], Ls[NX];
 #pragma unroll
         for (int l = 0; l < NX; l++) { L[l] = nL[l]; Ls[l] = nLs[l]; }
         const double g = ng;
         double dd = nd;                                // chol(k,0,t,t) unless refactorised below
-        if (k > 0 && active) {
+        if (k > 0) {
             // a failure in this block is not known yet; a group that fails stops
-            // using what it fetched, so the guess "still factorising" is harmless
-            const bool f = status == ST_OK && (k - 1 <= start);
-            const double* src = f ? I.hess : I.chol;
+            // using its results, so the guess "still factorising" is harmless
+            nextFromHess = __any(active && status == ST_OK && k - 1 <= start);
+            if (active) {
+                const double* src = nextFromHess ? I.hess : I.chol;
 #pragma unroll
-            for (int l = 0; l < NX; l++) {
-                nL[l] = HS(src, k - 1, 0, l, tc);
-                nLs[l] = HS(src, k - 1, -1, l, tc);
+                for (int l = 0; l < NX; l++) {
+                    nL[l] = HS(src, k - 1, 0, l, tc);
+                    nLs[l] = HS(src, k - 1, -1, l, tc);
+                }
+                ng = I.grad[(k - 1) * NX + tc];
+                nd = HS(I.chol, k - 1, 0, tc, tc);
             }
-            ng = I.grad[(k - 1) * NX + tc];
-            nd = HS(I.chol, k - 1, 0, tc, tc);
         }
-        if (__any(factorThis)) {
+        if (fromHess) {
             int failCol = -1;
-            factor_columns(L, Ls, Ln, factorThis, t, failCol, dd, Seq12{});
+            uint32_t ones = 0;
+            factor_columns<true>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: exercise the repeat path on every block
+            ones = 0xffffffffu;
+#endif
+            if (__any(ones == 0xffffffffu)) {
+                if (active) {
+#pragma unroll
+                    for (int l = 0; l < NX; l++) {
+                        L[l] = HS(I.hess, k, 0, l, tc);
+                        Ls[l] = HS(I.hess, k, -1, l, tc);
+                    }
+                }
+                failCol = -1;
+                factor_columns<false>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
+            }
             if (factorThis && col) {
 #pragma unroll
                 for (int l = 0; l < NX; l++)
