@@ -283,7 +283,7 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
             nLs[l] = HS(src, N - 1, -1, l, tc);
         }
         ng = I.grad[(N - 1) * NX + tc];
-        nd = HS(I.chol, N - 1, 0, tc, tc);
+        if (!nextFromHess) nd = HS(I.chol, N - 1, 0, tc, tc);
     }
 
     for (int k = N - 1; k >= 0; --k) {
@@ -306,7 +306,7 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
                     nLs[l] = HS(src, k - 1, -1, l, tc);
                 }
                 ng = I.grad[(k - 1) * NX + tc];
-                nd = HS(I.chol, k - 1, 0, tc, tc);
+                if (!nextFromHess) nd = HS(I.chol, k - 1, 0, tc, tc);
             }
         }
         if (fromHess) {
@@ -328,9 +328,10 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
                 factor_columns<false>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
             }
             if (factorThis && col) {
+                // whole rows: the entries right of the diagonal are zero in the
+                // reference's factor too (it never writes them)
 #pragma unroll
-                for (int l = 0; l < NX; l++)
-                    if (l >= t) HS(I.chol, k, 0, l, t) = L[l];
+                for (int l = 0; l < NX; l++) HS(I.chol, k, 0, l, t) = (l >= t) ? L[l] : 0.;
                 if (k > 0) {
 #pragma unroll
                     for (int l = 0; l < NX; l++) HS(I.chol, k, -1, l, t) = Ls[l];
