@@ -906,7 +906,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
                 }
             }
             __syncthreads();
-            if (tid < kTailPoints) slopes[tid] = accumulate_in_order<16>(0., terms + tid * ts, n);
+            if (tid < kTailPoints) slopes[tid] = accumulate_in_order<8>(0., terms + tid * ts, n);
             __syncthreads();
             // slopes stays untouched until the next round's accumulation, two
             // barriers from here
