@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcnmpc.so")
+# NMPC_AMD_LIB names another build of the same library (the parity tests load the
+# build whose factorisation always takes its plain-division path this way).
+LIB_PATH = os.environ.get("NMPC_AMD_LIB") or os.path.join(HERE, "libcnmpc.so")
 
 REAL = C.c_double
 PREAL = C.POINTER(C.c_double)

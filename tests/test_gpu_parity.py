@@ -496,6 +496,50 @@ def test_reference_points_from_waypoints(port_built):
     assert_same(g_two, g_host, "solver state, waypoints loaded in two calls")
 
 
+def test_plain_division_path_of_the_factorisation():
+    """The Newton factorisation takes root, reciprocal and quotients of a column
+    from one iteration and repeats a block with sqrt and plain divisions when a
+    root's significand is all ones, which random data never produces.
+    libcnmpc_repeat.so is the same source built to repeat every block: golden
+    sequences (with their final factor dumps) and a seeded batch must come out
+    bit for bit the same through it."""
+    lib = os.path.join(ROOT, "nmpc_amd", "libcnmpc_repeat.so")
+    assert os.path.exists(lib), "build it with `make -C nmpc_amd/csrc` (target all)"
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import assert_same, drive_gpu_batch, golden
+from nmpc_amd import _lib
+assert _lib.LIB_PATH.endswith("libcnmpc_repeat.so")
+for name in ("seq_straight", "seq_regularised", "seq_linesearch", "seq_bound"):
+    g = golden(name)
+    dump = "final_stages" in g
+    out = drive_gpu_batch([g], dump=dump)
+    assert_same(out["status"][0], g["status"], name + " status")
+    assert_same(out["iters"][0], g["iters"], name + " QP iterations")
+    assert_same(out["u"][0], g["u"], name + " controls")
+    if dump:
+        assert_same(out["final_globals"][0], g["final_globals"], name + " final solver state")
+import portdriver as P
+from nmpc_amd import synthetic as S
+from nmpc_amd.batch import Batch
+N, B = 40, 64
+d = S.make_batch(B, N, seed=5)
+cfg = S.setup_args()
+bt = Batch(B, N); bt.setup(**cfg); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
+bt.set_reference(d["refs"][:, :N + 1]); bt.solve(d["meas"][:, 0])
+u, st, it = bt.get_controls()
+eu, est, eit, _ = P.batch_cold_solve(N, cfg["state_weights"], cfg["control_weights"],
+    cfg["terminal_weights"], cfg["lower_control_bound"], cfg["upper_control_bound"],
+    d["refs"][:, :N + 1], d["meas"][:, 0], d["wind"], threads=8)
+assert_same(st, est, "status"); assert_same(it, eit, "QP iterations"); assert_same(u, eu, "controls")
+print("child ok")
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"))
+    env = dict(os.environ, NMPC_AMD_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_error_reporting():
     from nmpc_amd import _lib
     from nmpc_amd import synthetic as S
