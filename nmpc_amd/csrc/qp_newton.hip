@@ -55,7 +55,11 @@ NMPC_DEV double group_min(double x) {
 // pairs on gfx950 (tools/micro_div.hip): no difference.
 struct Pivot { double d, y; };
 NMPC_DEV bool plain_division_needed(double d) {
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: the substitutions divide plainly too
+    return true;
+#else
     return (__double_as_longlong(d) & 0xfffffffffffffLL) == 0xfffffffffffffLL;
+#endif
 }
 template <bool FAST>
 NMPC_DEV double divide(double n, const Pivot& p) {
