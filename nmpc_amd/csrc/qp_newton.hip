@@ -427,17 +427,24 @@ __global__ __launch_bounds__(kWave) void k_newton_solve(BatchView v) {
     const int last = I.sc->last;
     const int start = (live && last >= 0) ? (last < N - 1 ? last : N - 1) : -1;
 
-    double minDiag = kInfty;
-    int st = backward_pass(v, I, start, live, t, minDiag);
-    minDiag = group_min(minDiag);
-    const bool needReg = live && (st == ST_DIV_ZERO || minDiag < kDiagRegTol);
-    if (__any(needReg)) {
-        if (needReg && t < NX)
-            for (int k = 0; k < N; k++) HS(I.hess, k, 0, t, t) += kRegParam;
-        if (needReg && t == 0) I.sc->regularized = 1;
-        double unused = kInfty;
-        st = backward_pass(v, I, N - 1, needReg, t, unused);
-        if (needReg && st != ST_OK) {
+    // First sweep from each group's `start`; groups whose factor fails or has a
+    // small pivot regularise and take a second sweep over all blocks
+    // (dual_qp.c:601-698).  One loop, so that the sweep's code exists once.
+    bool sweep = live;
+    int from = start;
+    for (int pass = 0; pass < 2; ++pass) {
+        double minDiag = kInfty;
+        const int st = backward_pass(v, I, from, sweep, t, minDiag);
+        if (pass == 0) {
+            minDiag = group_min(minDiag);
+            const bool needReg = live && (st == ST_DIV_ZERO || minDiag < kDiagRegTol);
+            if (!__any(needReg)) break;
+            if (needReg && t < NX)
+                for (int k = 0; k < N; k++) HS(I.hess, k, 0, t, t) += kRegParam;
+            if (needReg && t == 0) I.sc->regularized = 1;
+            sweep = needReg;
+            from = N - 1;
+        } else if (sweep && st != ST_OK) {
             if (t == 0) I.sc->status = st;
             live = false;
         }
