@@ -94,44 +94,18 @@ inline size_t step_lds_bytes(int N) {
     return base + (NX * N <= kBufDoubles ? (size_t)(16 + 2 * NX * N) * sizeof(double) : 0);
 }
 
-// acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order.  The
-// LDS reads of the next AHEAD values are issued before the current ones are
-// added, and two register sets take turns so that no value is copied: a
-// wavefront on its own issues one instruction in four cycles, and with one read
-// and one add per value the loop runs at the latency of the dependent adds
-// (about 4 ns each on MI355X: an ordered sum of 1200 values costs 5 microseconds).
-template <int AHEAD = 8>
-NMPC_DEV double accumulate_in_order(double acc, const double* buf, int len) {
-    int t = 0;
-    if (len >= AHEAD) {
-        double c[AHEAD], nx[AHEAD];
-#pragma unroll
-        for (int i = 0; i < AHEAD; i++) c[i] = buf[i];
-        for (t = AHEAD; t + 2 * AHEAD <= len; t += 2 * AHEAD) {
-#pragma unroll
-            for (int i = 0; i < AHEAD; i++) nx[i] = buf[t + i];
-#pragma unroll
-            for (int i = 0; i < AHEAD; i++) acc += c[i];
-#pragma unroll
-            for (int i = 0; i < AHEAD; i++) c[i] = buf[t + AHEAD + i];
-#pragma unroll
-            for (int i = 0; i < AHEAD; i++) acc += nx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < AHEAD; i++) acc += c[i];
-    }
-    for (; t < len; t++) acc += buf[t];
-    return acc;
-}
-
-// The same sum by the sixteen lanes of a DPP row (all of them active, with the
-// same buf and len): each lane reads four consecutive values of a block of 64,
+// acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order, by
+// the sixteen lanes of a DPP row (all of them active, with the same acc, buf and
+// len).  A lane that reads the values itself pays an LDS instruction for every
+// two adds, and a wavefront on its own issues one instruction in about seven
+// cycles (7.2 ns per value measured, tools/micro_acc.hip).  Here each lane reads
+// four consecutive values of a block of 64,
 // and every lane then takes the 64 values in order through row broadcasts folded
 // into the add (v_fmac_f64 has a VOP2 form, which accepts a DPP row broadcast on
 // its first source, and acc + x * 1.0 rounds exactly as acc + x does).  One
 // instruction per value and no LDS access in the dependent chain: 5.3 ns per
-// value on MI355X against 7.2 for accumulate_in_order; the rows of a wavefront
-// run different sums side by side.  Every lane of the row returns the sum.
+// value on MI355X, 6.4 microseconds for 1200; the rows of a wavefront run
+// different sums side by side.  Every lane of the row returns the sum.
 template <int SRC>
 NMPC_DEV void add_row_value(double& acc, double x, double one) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
@@ -148,12 +122,11 @@ NMPC_DEV void add_row_block_partial(double& acc, const double (&c)[4], double on
                                     std::integer_sequence<int, I...>) {
     ((I < count ? add_row_value<I / 4>(acc, c[I % 4], one) : (void)0), ...);
 }
-NMPC_DEV double accumulate_by_row(const double* buf, int len) {
+NMPC_DEV double accumulate_by_row(double acc, const double* buf, int len) {
     using Seq64 = std::make_integer_sequence<int, 64>;
     const int l = threadIdx.x & 15;
     double one = 1.0;
     asm volatile("" : "+v"(one));               // keeps it in a vector register pair
-    double acc = 0.;
     double c[4], nx[4];
     auto fetch = [&](double (&d)[4], int t) {
 #pragma unroll
@@ -188,7 +161,7 @@ NMPC_DEV double block_ordered_sum(int n, const StageLds& L, F term) {
         }
         if (r < len) L.buf[r] = term(base + r);
         __syncthreads();
-        if (tid < kWave) acc = accumulate_in_order(acc, L.buf, len);
+        if (tid < kWave) acc = accumulate_by_row(acc, L.buf, len);
         __syncthreads();
     }
     if (tid == 0) L.red[0] = acc;
@@ -287,8 +260,8 @@ NMPC_DEV double stage_pass(const BatchView& v, const Inst& I, double a, const St
     // objective: stage values summed in horizon order
     if (tid < kWave) {
         // vals is slot-ordered: positions 0..N-1 are slots head..N-1, 0..head-1, then slot N
-        double acc = accumulate_in_order(0., L.vals + v.head, N - v.head);
-        acc = accumulate_in_order(acc, L.vals, v.head);
+        double acc = accumulate_by_row(0., L.vals + v.head, N - v.head);
+        acc = accumulate_by_row(acc, L.vals, v.head);
         acc += L.vals[N];
         if (tid == 0) L.red[0] = acc;
     }
@@ -659,9 +632,11 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
     }
     // objective (stage values in horizon order), slope and squared gradient norm,
     // side by side
-    if (tid < 3) {
-        const double* src = (tid == 0 || !rows) ? L.vals : (tid == 1 ? L.terms : L.sqr);
-        L.red[tid] = accumulate_in_order(0., src, (tid == 0 || !rows) ? N + 1 : NX * N);
+    if (tid < 3 * 16) {             // one DPP row each
+        const int w = tid >> 4;
+        const double* src = (w == 0 || !rows) ? L.vals : (w == 1 ? L.terms : L.sqr);
+        const double sv = accumulate_by_row(0., src, (w == 0 || !rows) ? N + 1 : NX * N);
+        if ((tid & 15) == 0) L.red[w] = sv;
     }
     __syncthreads();
     const double obj = L.red[0];
@@ -957,7 +932,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
             __syncthreads();
             if (tid < 8 * 16) {         // one DPP row per trial point (the eighth row idles along)
                 const int p = (tid >> 4) < kTailPoints ? (tid >> 4) : kTailPoints - 1;
-                const double sv = accumulate_by_row(terms + p * ts, n);
+                const double sv = accumulate_by_row(0., terms + p * ts, n);
                 if ((tid & 15) == 0 && (tid >> 4) < kTailPoints) slopes[p] = sv;
             }
             __syncthreads();
