@@ -654,8 +654,8 @@ constexpr int kTailElems = 2;
 constexpr int kTailDepth = 3;       // bisection levels settled per round
 constexpr int kTailPoints = (1 << kTailDepth) - 1;  // trial steps per round: a binary tree of outcomes
 constexpr int kTailMaxHorizon = 106;    // the tree's trial points and slope terms fill the 160 KB of LDS
-// Slope-term lists are accumulated side by side, one lane each; a stride that is
-// 5 mod 32 doubles keeps the lanes on different LDS banks.
+// Slope-term lists are accumulated side by side, one DPP row each; a stride that is
+// 5 mod 32 doubles keeps the rows on different LDS banks.
 NMPC_DEV int tail_term_stride(int n) { return n + ((5 - n % 32) + 32) % 32; }
 static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon + 32) * 8 + 64 <= 160 * 1024,
               "trial points and slope terms must fit LDS");
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 // rewritten by the commit anyway), and each round evaluates the next trial step
 // together with every step that can follow it within kTailDepth levels (a
 // binary tree: each trial is either left or right of the root of the slope),
-// so one round of ordered accumulations, which costs 8 microseconds however
+// so one round of ordered accumulations, which costs 6 microseconds however
 // many run side by side, settles kTailDepth levels.  Leaves the step length
 // and trial count in the instance's scalars for k_line_search_commit.
 __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, int nextIt) {
