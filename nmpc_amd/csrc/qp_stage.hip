@@ -657,7 +657,7 @@ constexpr int kTailMaxHorizon = 106;    // the tree's trial points and slope ter
 // Slope-term lists are accumulated side by side, one DPP row each; a stride that is
 // 5 mod 32 doubles keeps the rows on different LDS banks.
 NMPC_DEV int tail_term_stride(int n) { return n + ((5 - n % 32) + 32) % 32; }
-static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon + 32) * 8 + 64 <= 160 * 1024,
+static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon + 32) * 8 + 128 <= 160 * 1024,
               "trial points and slope terms must fit LDS");
 static_assert(NZ * (kTailMaxHorizon + 1) <= kTailElems * kTailThreads, "stage vectors must fit");
 static_assert(NX / 2 * kTailMaxHorizon <= kTailThreads, "two gradient rows per thread");
@@ -665,7 +665,7 @@ NMPC_DEV bool tail_capable(const BatchView& v) {
     return v.tailList != nullptr && v.N <= kTailMaxHorizon;
 }
 inline size_t tail_lds_bytes(int N) {
-    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(double) + 64;
+    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(double) + 128;
 }
 }  // namespace
 
@@ -842,6 +842,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
     double* terms = lds_raw + kTailPoints * E;              // [points][stride >= n] slope terms
     const int ts = tail_term_stride(n);
     double* slopes = terms + kTailPoints * ts;              // [points]
+    double* plan = slopes + 8;                              // [0] search over, [1..points] trial steps
     // gradient rows: thread t < 6 N owns rows h and h + 6 of block t / 6
     const int rk = tid / (NX / 2), rh = tid % (NX / 2);
     const bool rowOn = rk < N;
@@ -877,26 +878,38 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
             dlB = I.dl[rk * NX + rh + NX / 2];
         }
         settle(bs);
-        while (!bs.done) {
-            // this round's trial steps, heap order: node 1 is the next trial, nodes 2i
-            // and 2i+1 the trials after node i when its slope is negative / positive
+        // The search state lives in wavefront 0; the others only need each round's
+        // trial steps and the end of the search, which it leaves in LDS.
+        // Trial steps in heap order: node 1 is the next trial, nodes 2i and 2i+1
+        // the trials after node i when its slope is negative / positive.
+        auto plan_round = [&]() {
             double at[kTailPoints + 1];
-            {
-                Bisection st[kTailPoints + 1];
-                st[1] = bs;
+            Bisection st[kTailPoints + 1];
+            st[1] = bs;
 #pragma unroll
-                for (int i = 1; i <= kTailPoints; i++) {
-                    at[i] = st[i].done ? at[1] : trial_alpha(st[i]);
-                    if (2 * i + 1 <= kTailPoints) {
-                        st[2 * i] = st[i];
-                        st[2 * i + 1] = st[i];
-                        if (!st[i].done) {
-                            advance_assuming(st[2 * i], true);
-                            advance_assuming(st[2 * i + 1], false);
-                        }
+            for (int i = 1; i <= kTailPoints; i++) {
+                at[i] = st[i].done ? at[1] : trial_alpha(st[i]);
+                if (2 * i + 1 <= kTailPoints) {
+                    st[2 * i] = st[i];
+                    st[2 * i + 1] = st[i];
+                    if (!st[i].done) {
+                        advance_assuming(st[2 * i], true);
+                        advance_assuming(st[2 * i + 1], false);
                     }
                 }
             }
+            if (tid == 0) {
+#pragma unroll
+                for (int i = 1; i <= kTailPoints; i++) plan[i] = at[i];
+                plan[0] = bs.done ? 1. : 0.;
+            }
+        };
+        if (tid < kWave) plan_round();
+        __syncthreads();
+        while (plan[0] == 0.) {
+            double at[kTailPoints + 1];
+#pragma unroll
+            for (int i = 1; i <= kTailPoints; i++) at[i] = plan[i];
 #pragma unroll
             for (int m = 0; m < kTailElems; m++) {
                 const int e = tid + m * kTailThreads;
@@ -936,18 +949,23 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
                 if ((tid & 15) == 0 && (tid >> 4) < kTailPoints) slopes[p] = sv;
             }
             __syncthreads();
-            // slopes stays untouched until the next round's accumulation, two
-            // barriers from here
-            int node = 1;
+            // wavefront 0 walks down the tree along the slopes found and plans the
+            // next round; everyone has read this round's plan before the first
+            // barrier above
+            if (tid < kWave) {
+                int node = 1;
 #pragma unroll
-            for (int level = 0; level < kTailDepth; level++) {
-                if (!bs.done) {
-                    const double sv = slopes[node - 1];
-                    const bool neg = bs.phase == 0 ? (sv / normal < 0.) : !(sv > 0);
-                    advance(bs, sv, normal);
-                    node = 2 * node + (neg ? 0 : 1);
+                for (int level = 0; level < kTailDepth; level++) {
+                    if (!bs.done) {
+                        const double sv = slopes[node - 1];
+                        const bool neg = bs.phase == 0 ? (sv / normal < 0.) : !(sv > 0);
+                        advance(bs, sv, normal);
+                        node = 2 * node + (neg ? 0 : 1);
+                    }
                 }
+                plan_round();
             }
+            __syncthreads();
         }
         if (tid == 0) {
             I.sc->alpha = bs.alpha;
