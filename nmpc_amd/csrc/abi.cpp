@@ -98,6 +98,10 @@ struct nmpc_batch {
     // clear itself is postponed until something is about to read or partly
     // overwrite them, and dropped when every stage is linearised first.
     bool jacobians_zero_pending = false;
+    // nmpc_batch_init also re-stages every stage QP; a stage's linearisation
+    // rewrites all of that, so the stages 0..N-1 are left for later under the
+    // same rule (k_init_stages part 2).
+    bool stage_init_pending = false;
     // Likewise for nmpc_batch_reset: the stage vectors zLow .. y are logically
     // zero after it, but nmpc_batch_init rewrites six of the nine, the first
     // feedback step rewrites z and y, and the trial-point scratch is never
@@ -209,8 +213,17 @@ int materialise_stage_vectors(nmpc_batch* b) {
     return 0;
 }
 
-// Carries out the postponed clear of C and c.
+int timed_init_part2(nmpc_batch* b) {
+    return timed(b, NMPC_K_OTHER, [&] { launch_init_stages(b->v, 2, b->stream); });
+}
+
+// Carries out the postponed clear of C and c and the postponed re-staging of
+// the stages 0..N-1.
 int materialise_jacobians(nmpc_batch* b) {
+    if (b->stage_init_pending) {
+        b->stage_init_pending = false;
+        if (int rc = timed_init_part2(b)) return rc;
+    }
     if (!b->jacobians_zero_pending) return 0;
     const BatchView& v = b->v;
     HIP_TRY(hipMemsetAsync(v.C, 0, (size_t)v.B * v.N * 180 * sizeof(double), b->stream));
@@ -329,6 +342,7 @@ int nmpc_batch_reset(nmpc_batch_t* b) {
     HIP_TRY(hipMemsetAsync(v.p, 0, (size_t)(base + b->reset_bytes - (char*)v.p), b->stream));
     b->stage_zero_pending = true;
     b->zy_zero_pending = false;
+    b->stage_init_pending = false;      // what it would write is zero again
     b->v.head = b->v.xhead = b->v.lhead = 0;
     b->initialised = false;
     return 0;
@@ -371,7 +385,8 @@ int nmpc_batch_init(nmpc_batch_t* b) {
         b->stage_zero_pending = false;
         b->zy_zero_pending = true;
     }
-    TRY(timed(b, NMPC_K_OTHER, [&] { launch_init_stages(v, b->stream); }));
+    TRY(timed(b, NMPC_K_OTHER, [&] { launch_init_stages(v, 1, b->stream); }));
+    b->stage_init_pending = true;
     b->initialised = true;
     return 0;
 }
@@ -404,7 +419,7 @@ int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_
     const int lin_first = first == 0 ? 0 : (int)first - 1;
     const int lin_count = first == 0 ? (int)count - 1 : (int)count;
     if (lin_first == 0 && lin_count == b->v.N)
-        b->jacobians_zero_pending = false;      // every stage is rewritten below
+        b->jacobians_zero_pending = b->stage_init_pending = false;  // every stage is rewritten below
     else
         TRY(materialise_jacobians(b));
     if (lin_count > 0)
@@ -448,7 +463,7 @@ int nmpc_batch_relinearise(nmpc_batch_t* b) {
     if (!b->initialised) return fail(NMPC_E_STATE, "nmpc_batch_relinearise before nmpc_batch_init");
     TRY(use_device(b));
     sync_config(b);
-    b->jacobians_zero_pending = false;      // every stage is rewritten
+    b->jacobians_zero_pending = b->stage_init_pending = false;      // every stage is rewritten
     TRY(timed(b, NMPC_K_LINEARISE, [&] { launch_linearise(b->v, 0, b->v.N, b->stream); }));
     return 0;
 }

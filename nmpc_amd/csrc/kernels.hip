@@ -94,14 +94,19 @@ __global__ void k_store_refs(BatchView v, const double* __restrict__ refs,
 // qStep := C' lambda_{k+1} - lambda_k + g, pStep := c . lambda_{k+1},
 // dz := -(qStep / H), zUnc := 0) multiplies the multipliers by literal zeros.
 // One thread per (instance, position, variable): contiguous stores.
-__global__ void k_init_stages(BatchView v) {
+// Linearising a stage rewrites every vector this kernel writes for it, so the
+// host runs the kernel in two parts: the active-set record and the terminal
+// stage at once (part 1), the stages 0..N-1 (part 2) only if something turns up
+// that reads them before every stage has been linearised.
+__global__ void k_init_stages(BatchView v, int part) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = (v.N + 1) * NZ;
     if (t >= (long)v.B * per) return;
     const int b = (int)(t / per), r = (int)(t % per);
     const int k = r / NZ, i = r - k * NZ;
     Inst I = instance(v, b);
-    I.prev[r] = -42;
+    if (part == 1) I.prev[r] = -42;
+    if ((part == 1) != (k == v.N)) return;
     const int nV = k < v.N ? NZ : NX;
     if (i >= nV) return;
     const int s = stage_slot(v, k);
@@ -325,9 +330,9 @@ void launch_refs_from_waypoints(int B, const double* wp, int W, double t0, doubl
     hipLaunchKernelGGL(k_refs_from_waypoints, dim3(blocks_for(n, 256)), dim3(256), 0, s, B, wp, W, t0,
                        dt, first, count, out);
 }
-void launch_init_stages(const BatchView& v, hipStream_t s) {
+void launch_init_stages(const BatchView& v, int part, hipStream_t s) {
     const long n = (long)v.B * (v.N + 1) * NZ;
-    hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 256)), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, part);
 }
 void launch_linearise(const BatchView& v, int first, int count, hipStream_t s) {
     const long n = (long)v.B * count * 16;

@@ -11,7 +11,7 @@ struct Bounds { double lb[3], ub[3]; };
 void launch_store_refs(const BatchView& v, const double* refs, int first, int count, hipStream_t s);
 void launch_refs_from_waypoints(int B, const double* wp, int W, double t0, double dt, int first,
                                 int count, double* out, hipStream_t s);
-void launch_init_stages(const BatchView& v, hipStream_t s);
+void launch_init_stages(const BatchView& v, int part, hipStream_t s);
 void launch_linearise(const BatchView& v, int first, int count, hipStream_t s);
 void launch_linearise_free(long n, const double* x, const double* u, const double* xnext,
                            const double* wind, const Bounds& bnd, double* jac, double* res,
