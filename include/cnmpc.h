@@ -231,6 +231,9 @@ enum {
     NMPC_K_NEWTON_STEP, NMPC_K_OTHER, NMPC_K_COUNT
 };
 int nmpc_batch_set_profiling(nmpc_batch_t *b, int enabled);
+/* Restricts the timing to the kernel ids whose bit is set in `kinds` (0: all of
+ * them again).  Every timed launch costs two event packets on the stream. */
+int nmpc_batch_set_profiling_kinds(nmpc_batch_t *b, unsigned kinds);
 /* Waits for the stream; total_ms / launches since profiling was last enabled. */
 int nmpc_batch_get_kernel_time(nmpc_batch_t *b, int kernel, double *total_ms,
                                uint64_t *launches);

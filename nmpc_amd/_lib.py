@@ -96,6 +96,7 @@ PROTOTYPES = {
     "nmpc_batch_get_global": (C.c_int, [C.c_void_p, C.c_uint32, PREAL]),
     "nmpc_batch_get_solver_info": (C.c_int, [C.c_void_p, C.c_uint32, PI32, PREAL]),
     "nmpc_batch_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "nmpc_batch_set_profiling_kinds": (C.c_int, [C.c_void_p, C.c_uint]),
     "nmpc_batch_get_kernel_time": (C.c_int, [C.c_void_p, C.c_int, PREAL,
                                              C.POINTER(C.c_uint64)]),
     "nmpc_linearise_samples": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64] +

@@ -199,7 +199,12 @@ class Batch:
         return d
 
     # -- profiling -------------------------------------------------------
-    def set_profiling(self, enabled=True):
+    def set_profiling(self, enabled=True, kinds=None):
+        """Per-kernel timing on or off; kinds: names of the kernels to time (all if None)."""
+        mask = 0
+        for name in kinds or ():
+            mask |= 1 << _lib.KERNEL_NAMES.index(name)
+        self._ck(self.lib.nmpc_batch_set_profiling_kinds(self.h, mask))
         self._ck(self.lib.nmpc_batch_set_profiling(self.h, 1 if enabled else 0))
 
     def kernel_times(self):

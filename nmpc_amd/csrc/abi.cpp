@@ -111,6 +111,7 @@ struct nmpc_batch {
     double* plant = nullptr;    // [B][13] simulated vehicle states (nmpc_batch_plant_*)
     double* plant_next = nullptr;   // output of the next roll-forward step, then swapped
     bool profiling = false;
+    unsigned profile_kinds = ~0u;   // bit k: launches of kernel id k are timed
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
     bool chain_launches = false;    // inside a sequence of launches with nothing between them
@@ -140,9 +141,10 @@ int get_event(nmpc_batch* b, hipEvent_t* e) {
 // HIP events whose elapsed time is charged to `kind`.
 template <class F>
 int timed_on(nmpc_batch* b, hipStream_t stream, int kind, F launch) {
-    if (!b->profiling) {
+    if (!b->profiling || !((b->profile_kinds >> kind) & 1u)) {
         launch();
         HIP_TRY(hipGetLastError());
+        b->chain_event = nullptr;       // the next timed launch starts its own interval
         return 0;
     }
     TimedLaunch t{kind, nullptr, nullptr, true};
@@ -731,6 +733,15 @@ int nmpc_batch_set_profiling(nmpc_batch_t* b, int enabled) {
     b->profiling = enabled != 0;
     if (enabled)
         for (int i = 0; i < NMPC_K_COUNT; i++) { b->k_ms[i] = 0; b->k_count[i] = 0; }
+    return 0;
+}
+
+int nmpc_batch_set_profiling_kinds(nmpc_batch_t* b, unsigned kinds) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    TRY(use_device(b));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    TRY(drain_timings(b));
+    b->profile_kinds = kinds ? kinds : ~0u;
     return 0;
 }
 
