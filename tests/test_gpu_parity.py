@@ -574,4 +574,18 @@ def test_kernel_timing_interface():
     t = bt.kernel_times()
     assert t["linearise"][1] == 1 and t["linearise"][0] > 0
     assert t["newton_solve"][1] == 5 and t["qp_begin"][1] == 1
+    u_all = bt.get_controls()
+    # timing restricted to one kernel: the others report nothing, results unchanged
+    bt.reset()
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.set_profiling(True, kinds=["newton_solve"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    bt.solve(d["meas"][:, 0])
+    t = bt.kernel_times()
+    assert t["newton_solve"][1] == 5 and t["newton_solve"][0] > 0
+    assert all(n == 0 for k, (ms, n) in t.items() if k != "newton_solve")
+    for a, b, what in zip(u_all, bt.get_controls(), ("controls", "status", "iterations")):
+        assert_same(b, a, what)
+    bt.set_profiling(False)
     bt.close()
