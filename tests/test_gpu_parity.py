@@ -540,6 +540,51 @@ print("child ok")
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_two_batches_interleaved(port_built):
+    """Two batches of different shapes in one process, their calls interleaved
+    (each on its own stream): neither disturbs the other."""
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    shapes = ((70, 100, 11), (33, 40, 12))
+    data = [S.make_batch(B, N, extra_steps=2, seed=seed) for B, N, seed in shapes]
+    bts = []
+    for (B, N, _), d in zip(shapes, data):
+        bt = Batch(B, N)
+        bt.setup(**S.setup_args())
+        bts.append(bt)
+    for bt in bts:
+        bt.initialise_horizon()
+    for bt, d in zip(bts, data):
+        bt.set_wind_velocity(d["wind"])
+    for bt, (B, N, _), d in zip(bts, shapes, data):
+        bt.set_reference(d["refs"][:, :N + 1])
+    got = [[], []]
+    for k in range(3):
+        for bt, d in zip(bts, data):
+            bt.solve(d["meas"][:, k])
+        for i, (bt, (B, N, _), d) in enumerate(zip(bts, shapes, data)):
+            got[i].append(bt.get_controls())
+            if k < 2:
+                bt.update_horizon(d["refs"][:, N + 1 + k])
+    for i, ((B, N, _), d) in enumerate(zip(shapes, data)):
+        alone = Batch(B, N)
+        alone.setup(**S.setup_args())
+        alone.initialise_horizon()
+        alone.set_wind_velocity(d["wind"])
+        alone.set_reference(d["refs"][:, :N + 1])
+        for k in range(3):
+            alone.solve(d["meas"][:, k])
+            for a, b, what in zip(alone.get_controls(), got[i][k], ("controls", "status", "iterations")):
+                assert_same(b, a, "batch %d step %d %s" % (i, k, what))
+            if k < 2:
+                alone.update_horizon(d["refs"][:, N + 1 + k])
+        alone.close()
+    eu, est, eit, _ = _port_cold(data[1], shapes[1][1])
+    assert_same(got[1][0][0], eu, "first solve of batch 1 against the oracle")
+    for bt in bts:
+        bt.close()
+
+
 def test_error_reporting():
     from nmpc_amd import _lib
     from nmpc_amd import synthetic as S
