@@ -53,6 +53,7 @@ class Batch:
             C.byref(h), self.B, self.N, int(device),
             C.c_void_p(stream) if stream else None))
         self.h = h
+        self._own_stream = not stream
         self._keep = []
 
     def close(self):
@@ -69,6 +70,21 @@ class Batch:
     def _ck(self, rc):
         _lib.check(self.lib, rc)
 
+    def _arg(self, x, shape):
+        """Input argument; a device tensor is kept alive until the next wait.  A
+        batch on its own stream is not ordered behind the torch stream that
+        produced the tensor, so that stream is drained first (pass torch's stream
+        to Batch() to avoid the wait)."""
+        a = _Arg(x, shape)
+        if _is_torch(x):
+            if self._own_stream:
+                import torch
+                torch.cuda.current_stream(x.device).synchronize()
+            if len(self._keep) >= 256:      # bounded keep-alive list
+                self.synchronize()
+            self._keep.append(a)
+        return a
+
     # -- configuration -------------------------------------------------
     def setup(self, state_weights, control_weights, terminal_weights,
               upper_control_bound, lower_control_bound):
@@ -83,18 +99,16 @@ class Batch:
         self._ck(self.lib.nmpc_batch_init(self.h))
 
     def set_wind_velocity(self, wind):
-        a = _Arg(wind, (self.B, 3))
+        a = self._arg(wind, (self.B, 3))
         self._ck(self.lib.nmpc_batch_set_wind_velocity(self.h, a.ptr))
-        self._keep = [a]
 
     def set_reference(self, points, first=0):
         """points [B][count][16] -> horizon positions first .. first+count-1."""
         shp = tuple(points.shape)
         if len(shp) != 3 or shp[0] != self.B or shp[2] != 16:
             raise ValueError("expected [B][count][16]")
-        a = _Arg(points, shp)
+        a = self._arg(points, shp)
         self._ck(self.lib.nmpc_batch_set_reference_points(self.h, a.ptr, int(first), shp[1]))
-        self._keep.append(a)
 
     def set_reference_from_waypoints(self, waypoints, t0, dt, first=0, count=None):
         """waypoints [B][W][17] rows (t, 16-vector), sorted by t: horizon positions
@@ -103,10 +117,9 @@ class Batch:
         if len(shp) != 3 or shp[0] != self.B or shp[2] != 17:
             raise ValueError("expected [B][W][17]")
         count = self.N + 1 - first if count is None else count
-        a = _Arg(waypoints, shp)
+        a = self._arg(waypoints, shp)
         self._ck(self.lib.nmpc_batch_set_reference_from_waypoints(
             self.h, a.ptr, shp[1], float(t0), float(dt), int(first), int(count)))
-        self._keep.append(a)
 
     # -- control loop --------------------------------------------------
     def prepare(self):
@@ -118,9 +131,8 @@ class Batch:
         self._ck(self.lib.nmpc_batch_relinearise(self.h))
 
     def solve(self, measurement):
-        a = _Arg(measurement, (self.B, 13))
+        a = self._arg(measurement, (self.B, 13))
         self._ck(self.lib.nmpc_batch_feedback_step(self.h, a.ptr))
-        self._keep.append(a)
 
     def get_controls(self):
         """-> (controls [B][3], status [B] (0 ok / 1 infeasible), iterations [B])"""
@@ -130,26 +142,24 @@ class Batch:
         self._ck(self.lib.nmpc_batch_get_controls(
             self.h, C.c_void_p(u.ctypes.data), C.c_void_p(st.ctypes.data),
             C.c_void_p(it.ctypes.data)))
-        self._keep = []
+        self._keep = []         # host outputs: the call waited for the stream
         return u, st, it
 
     def get_controls_into(self, controls, status, iterations):
-        """Device-resident outputs (torch CUDA tensors: f64 [B][3], i32 [B], i32 [B])."""
+        """Device-resident outputs (torch CUDA tensors: f64 [B][3], i32 [B], i32 [B]),
+        written on the batch's stream; the call does not wait for them."""
         self._ck(self.lib.nmpc_batch_get_controls(
             self.h, C.c_void_p(controls.data_ptr()), C.c_void_p(status.data_ptr()),
             C.c_void_p(iterations.data_ptr())))
-        self._keep = []
 
     def update_horizon(self, new_reference):
-        a = _Arg(new_reference, (self.B, 16))
+        a = self._arg(new_reference, (self.B, 16))
         self._ck(self.lib.nmpc_batch_update_horizon(self.h, a.ptr))
-        self._keep.append(a)
 
     # -- plant roll-forward (closed loop on the device) ---------------------
     def plant_set_state(self, states):
-        a = _Arg(states, (self.B, 13))
+        a = self._arg(states, (self.B, 13))
         self._ck(self.lib.nmpc_batch_plant_set_state(self.h, a.ptr))
-        self._keep.append(a)
 
     def plant_state(self):
         x = np.zeros((self.B, 13))
@@ -159,11 +169,10 @@ class Batch:
     def plant_integrate(self, dt, controls=None, wind=None):
         """One RK4 step of every simulated vehicle.  controls None: the last good
         controls of each controller; wind None: the controllers' wind estimate."""
-        ac = _Arg(controls, (self.B, 3)) if controls is not None else None
-        aw = _Arg(wind, (self.B, 3)) if wind is not None else None
+        ac = self._arg(controls, (self.B, 3)) if controls is not None else None
+        aw = self._arg(wind, (self.B, 3)) if wind is not None else None
         self._ck(self.lib.nmpc_batch_plant_integrate(
             self.h, float(dt), ac.ptr if ac else None, aw.ptr if aw else None))
-        self._keep += [a for a in (ac, aw) if a]
 
     def solve_from_plant(self):
         self._ck(self.lib.nmpc_batch_feedback_step_from_plant(self.h))

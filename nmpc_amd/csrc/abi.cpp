@@ -92,6 +92,7 @@ struct nmpc_batch {
     size_t arena_bytes = 0;
     size_t reset_bytes = 0;     // leading part of the arena that nmpc_batch_reset clears
     double wq[12], wr[3], wt[12], lb[3], ub[3];
+    double init_lb[3], init_ub[3];      // control bounds as nmpc_batch_init saw them
     bool initialised = false;
     Staging in_refs, in_meas, in_wind, out_u, out_status, out_iters, scratch;
     // nmpc_batch_init leaves the Jacobians C and residuals c logically zero; the
@@ -215,8 +216,13 @@ int materialise_stage_vectors(nmpc_batch* b) {
     return 0;
 }
 
+// The stage bounds nmpc_init writes are the control bounds of that moment
+// (ccs-c66x/cnmpc.c:920-931), whatever the setters have been given since.
 int timed_init_part2(nmpc_batch* b) {
-    return timed(b, NMPC_K_OTHER, [&] { launch_init_stages(b->v, 2, b->stream); });
+    BatchView at_init = b->v;
+    memcpy(at_init.lb, b->init_lb, sizeof at_init.lb);
+    memcpy(at_init.ub, b->init_ub, sizeof at_init.ub);
+    return timed(b, NMPC_K_OTHER, [&] { launch_init_stages(at_init, 2, b->stream); });
 }
 
 // Carries out the postponed clear of C and c and the postponed re-staging of
@@ -380,6 +386,8 @@ int nmpc_batch_init(nmpc_batch_t* b) {
     const bool idt = is_identity(b->wt, 12);
     for (int i = 0; i < 12; i++) v.Ht[i] = idt ? 1. : b->wt[i];
     sync_config(b);
+    memcpy(b->init_lb, b->lb, sizeof b->init_lb);
+    memcpy(b->init_ub, b->ub, sizeof b->init_ub);
     v.head = 0;   // the interval order is rebuilt (ccs-c66x/cnmpc.c:817-828)
     // Jacobians and residuals start at zero (ccs-c66x/cnmpc.c:913-917)
     b->jacobians_zero_pending = true;
@@ -402,20 +410,13 @@ int nmpc_batch_set_wind_velocity(nmpc_batch_t* b, const real_t* wind) {
     return 0;
 }
 
-int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_t first,
-                                    uint32_t count) {
-    if (!b || !refs) return fail(NMPC_E_ARG, "nmpc_batch_set_reference_points: null argument");
-    if (count == 0) return 0;
-    if ((uint64_t)first + count > (uint64_t)b->v.N + 1)
-        return fail(NMPC_E_ARG, "reference index %u beyond horizon %d", first + count - 1, b->v.N);
-    TRY(use_device(b));
+// Reference points already in device memory ([B][count][16]) -> rings, then the
+// linearisation of the stages they complete.
+static int store_and_linearise(nmpc_batch* b, const double* dev, uint32_t first, uint32_t count) {
     sync_config(b);
     if (b->stage_zero_pending) TRY(materialise_stage_vectors(b));
-    const void* dev = nullptr;
-    const bool host = !is_device_pointer(refs);
-    TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(double), &dev));
     TRY(timed(b, NMPC_K_OTHER, [&] {
-        launch_store_refs(b->v, (const double*)dev, (int)first, (int)count, b->stream);
+        launch_store_refs(b->v, dev, (int)first, (int)count, b->stream);
     }));
     // point i linearises stage i-1
     const int lin_first = first == 0 ? 0 : (int)first - 1;
@@ -428,6 +429,20 @@ int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_
         TRY(timed(b, NMPC_K_LINEARISE, [&] {
             launch_linearise(b->v, lin_first, lin_count, b->stream);
         }));
+    return 0;
+}
+
+int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_t first,
+                                    uint32_t count) {
+    if (!b || !refs) return fail(NMPC_E_ARG, "nmpc_batch_set_reference_points: null argument");
+    if (count == 0) return 0;
+    if ((uint64_t)first + count > (uint64_t)b->v.N + 1)
+        return fail(NMPC_E_ARG, "reference index %u beyond horizon %d", first + count - 1, b->v.N);
+    TRY(use_device(b));
+    const void* dev = nullptr;
+    const bool host = !is_device_pointer(refs);
+    TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(double), &dev));
+    TRY(store_and_linearise(b, (const double*)dev, first, count));
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));   // caller may reuse its buffer
     return 0;
 }
@@ -450,7 +465,7 @@ int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t* b, const real_t* waypo
         launch_refs_from_waypoints((int)B, (const double*)dwp, (int)n_waypoints, t0, dt, (int)first,
                                    (int)count, (double*)b->scratch.ptr, b->stream);
     }));
-    TRY(nmpc_batch_set_reference_points(b, (const real_t*)b->scratch.ptr, first, count));
+    TRY(store_and_linearise(b, (const double*)b->scratch.ptr, first, count));
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -508,9 +523,9 @@ int nmpc_batch_get_controls(nmpc_batch_t* b, real_t* controls, int32_t* status,
     const bool du = controls && is_device_pointer(controls);
     const bool ds = status && is_device_pointer(status);
     const bool di = iterations && is_device_pointer(iterations);
-    TRY(b->out_u.reserve(B * 3 * sizeof(double)));
-    TRY(b->out_status.reserve(B * sizeof(int)));
-    TRY(b->out_iters.reserve(B * sizeof(int)));
+    if (!du) TRY(b->out_u.reserve(B * 3 * sizeof(double)));
+    if (!ds) TRY(b->out_status.reserve(B * sizeof(int)));
+    if (!di) TRY(b->out_iters.reserve(B * sizeof(int)));
     double* pu = du ? controls : (double*)b->out_u.ptr;
     int* ps = ds ? status : (int*)b->out_status.ptr;
     int* pi = di ? iterations : (int*)b->out_iters.ptr;
@@ -521,7 +536,8 @@ int nmpc_batch_get_controls(nmpc_batch_t* b, real_t* controls, int32_t* status,
         HIP_TRY(hipMemcpyAsync(status, ps, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     if (iterations && !di)
         HIP_TRY(hipMemcpyAsync(iterations, pi, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    const bool any_host = (controls && !du) || (status && !ds) || (iterations && !di);
+    if (any_host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
 

@@ -24,10 +24,6 @@
 
 namespace nmpc {
 
-namespace {
-
-}  // namespace
-
 // ------------------------------------------------------------------------
 // Reference points from waypoints (interpolate_reference of the reference's
 // harness, scripts/nmpc-xplane-synthetic.py:62-78): waypoints [B][W][17] rows
@@ -269,10 +265,8 @@ __global__ __launch_bounds__(256) void k_rk4_free(long n, const double* __restri
     for (int i = 0; i < NS; i++) out[t * NS + i] = r[i];
 }
 
-// ========================================================================
-// Dual Newton solve, one wavefront per instance.
 // ------------------------------------------------------------------------
-// One thread per instance.
+// End of a solve (dual_qp.c:219-222, cnmpc.c:705-726).  One thread per instance.
 __global__ void k_qp_finish(BatchView v) {
     const int b = v.b0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= v.b0 + v.nb) return;

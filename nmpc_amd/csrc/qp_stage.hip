@@ -971,6 +971,8 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
             I.sc->alpha = bs.alpha;
             I.sc->lsIter = bs.it;
         }
+        // every wavefront has read plan[0] of this item before wavefront 0 plans the next one
+        __syncthreads();
     }
 }
 

@@ -1,0 +1,70 @@
+"""GPU parity tests (pytest -m gpu) of shapes and call orders beyond
+test_gpu_parity.py: the per-GPU share of the 8-GPU configuration and control
+bounds changed between initialisation and reference loading."""
+import numpy as np
+import pytest
+
+from helpers import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def test_per_gpu_share_of_the_8_gpu_configuration(port_built):
+    """32 768 instances, horizon 100: what each rank of the 262 144-instance
+    configuration runs.  Every instance against the CPU oracle."""
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B = 100, 32768
+    d = S.make_batch(B, N, seed=S.DEFAULT_SEED + 3)
+    cfg = S.setup_args()
+    bt = Batch(B, N)
+    bt.setup(**cfg)
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    bt.solve(d["meas"][:, 0])
+    u, st, it = bt.get_controls()
+    bt.close()
+    eu, est, eit, _ = P.batch_cold_solve(
+        N, cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+        cfg["lower_control_bound"], cfg["upper_control_bound"], d["refs"][:, :N + 1],
+        d["meas"][:, 0], d["wind"], threads=16)
+    assert_same(st, est, "status")
+    assert_same(it, eit, "QP iterations")
+    assert_same(u, eu, "controls")
+    assert (st == 0).sum() > B // 2
+
+
+def test_bounds_changed_between_init_and_partial_reference_loading(port_built):
+    """nmpc_init fixes the stage bounds from the control bounds of that moment
+    (ccs-c66x/cnmpc.c:920-931); bounds set afterwards reach only the stages
+    linearised afterwards (cnmpc.c:1053-1062).  The library postpones part of
+    its initialisation, which must not let later bounds leak into it."""
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B = 12, 3
+    d = S.make_batch(B, N, seed=91, turn_start=(0.05, 0.2))
+    cfg = S.setup_args()
+    lo2, up2 = [0.1, 0.2, 0.3], [0.9, 0.8, 0.7]
+    bt = Batch(B, N)
+    bt.setup(**cfg)
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.setup(**dict(cfg, lower_control_bound=lo2, upper_control_bound=up2))
+    bt.set_reference(d["refs"][:, :5])          # stages 0..3 only
+    got = [bt.stages(b) for b in range(B)]
+    bt.close()
+    for b in range(B):
+        c = P.Port(N)
+        c.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        c.init()
+        c.set_wind(d["wind"][b])
+        c.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"], up2, lo2)
+        for i in range(5):
+            c.set_reference(d["refs"][b, i], i)
+        exp = c.stages()
+        assert_same(got[b], exp, "stage records, instance %d" % b)
+        assert (exp[6, 204:207] == 0.0).all() and (exp[1, 204:207] != 0.0).all()
