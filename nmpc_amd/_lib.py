@@ -80,6 +80,8 @@ PROTOTYPES = {
                                                   C.c_uint32]),
     "nmpc_batch_set_reference_from_waypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, REAL,
                                                           REAL, C.c_uint32, C.c_uint32]),
+    "nmpc_batch_set_reference_from_waypoints_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32,
+                                                                  REAL, REAL, C.c_uint32, C.c_uint32]),
     "nmpc_batch_preparation_step": (C.c_int, [C.c_void_p]),
     "nmpc_batch_relinearise": (C.c_int, [C.c_void_p]),
     "nmpc_batch_feedback_step": (C.c_int, [C.c_void_p, C.c_void_p]),

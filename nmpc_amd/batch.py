@@ -121,6 +121,18 @@ class Batch:
         self._ck(self.lib.nmpc_batch_set_reference_from_waypoints(
             self.h, a.ptr, shp[1], float(t0), float(dt), int(first), int(count)))
 
+    def set_reference_from_waypoints_noalloc(self, waypoints, t0, dt, first=0, count=None):
+        """The same for callers that cannot allocate device memory: device
+        waypoints only, at most NMPC_STATIC_SCRATCH_POINTS = 65536 points
+        (instances x count) per call."""
+        shp = tuple(waypoints.shape)
+        if len(shp) != 3 or shp[0] != self.B or shp[2] != 17:
+            raise ValueError("expected [B][W][17]")
+        count = self.N + 1 - first if count is None else count
+        a = self._arg(waypoints, shp)
+        self._ck(self.lib.nmpc_batch_set_reference_from_waypoints_noalloc(
+            self.h, a.ptr, shp[1], float(t0), float(dt), int(first), int(count)))
+
     # -- control loop --------------------------------------------------
     def prepare(self):
         self._ck(self.lib.nmpc_batch_preparation_step(self.h))

@@ -115,6 +115,7 @@ struct nmpc_batch {
     unsigned profile_kinds = ~0u;   // bit k: launches of kernel id k are timed
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
+    bool untimed = false;           // inside an entry point that must not create events
     bool chain_launches = false;    // inside a sequence of launches with nothing between them
     hipEvent_t chain_event = nullptr;
     double k_ms[NMPC_K_COUNT] = {0};
@@ -142,7 +143,7 @@ int get_event(nmpc_batch* b, hipEvent_t* e) {
 // HIP events whose elapsed time is charged to `kind`.
 template <class F>
 int timed_on(nmpc_batch* b, hipStream_t stream, int kind, F launch) {
-    if (!b->profiling || !((b->profile_kinds >> kind) & 1u)) {
+    if (!b->profiling || b->untimed || !((b->profile_kinds >> kind) & 1u)) {
         launch();
         HIP_TRY(hipGetLastError());
         b->chain_event = nullptr;       // the next timed launch starts its own interval
@@ -468,6 +469,66 @@ int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t* b, const real_t* waypo
     TRY(store_and_linearise(b, (const double*)b->scratch.ptr, first, count));
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
+}
+
+// ---- the entry point that allocates nothing -------------------------------------
+// The interpolated reference points of nmpc_batch_set_reference_from_waypoints
+// pass from one kernel to the next through a buffer the library allocates on
+// demand.  Here that buffer is a fixed array in the code object: 65 536 points
+// of 16 doubles, 8 MiB on every GPU the library runs on, held until the
+// process ends and shared by all batches on that GPU.
+constexpr uint32_t kStaticPoints = NMPC_STATIC_SCRATCH_POINTS;
+static __device__ __align__(256) double scratch[(size_t)kStaticPoints * 16];
+constexpr int kMaxDevices = 64;
+static double* g_scratch_ptr[kMaxDevices];      // device address of `scratch`, per GPU
+
+// The array's name is only a handle on the host; its memory on the current
+// device is found once per device.
+static int static_scratch(int device, double** out) {
+    if (device < 0 || device >= kMaxDevices)
+        return fail(NMPC_E_ARG, "device %d beyond the %d the library keeps scratch addresses for",
+                    device, kMaxDevices);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(NMPC_E_HIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[device] = (double*)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
+int nmpc_batch_set_reference_from_waypoints_noalloc(nmpc_batch_t* b, const real_t* waypoints,
+                                                    uint32_t n_waypoints, real_t t0, real_t dt,
+                                                    uint32_t first, uint32_t count) {
+    if (!b || !waypoints || n_waypoints == 0)
+        return fail(NMPC_E_ARG, "nmpc_batch_set_reference_from_waypoints_noalloc: null or empty argument");
+    if (count == 0) return 0;
+    if ((uint64_t)first + count > (uint64_t)b->v.N + 1)
+        return fail(NMPC_E_ARG, "reference index %u beyond horizon %d", first + count - 1, b->v.N);
+    const uint64_t points = (uint64_t)b->v.B * count;
+    if (points > kStaticPoints)
+        return fail(NMPC_E_ARG, "nmpc_batch_set_reference_from_waypoints_noalloc: %llu reference "
+                    "points (instances x count) exceed the fixed scratch of %u points; load fewer "
+                    "points per call or use nmpc_batch_set_reference_from_waypoints",
+                    (unsigned long long)points, kStaticPoints);
+    TRY(use_device(b));
+    if (!is_device_pointer(waypoints))
+        return fail(NMPC_E_ARG, "nmpc_batch_set_reference_from_waypoints_noalloc: waypoints must be "
+                    "device memory (a host buffer would need a staging allocation)");
+    double* points_dev = nullptr;
+    TRY(static_scratch(b->device, &points_dev));
+    struct Untimed {        // timing a launch may create events
+        nmpc_batch* b;
+        explicit Untimed(nmpc_batch* bb) : b(bb) { b->untimed = true; }
+        ~Untimed() { b->untimed = false; }
+    } untimed(b);
+    // every entry of the points the kernels below read is written first: nothing
+    // of an earlier call's contents is looked at
+    launch_refs_from_waypoints(b->v.B, (const double*)waypoints, (int)n_waypoints, t0, dt, (int)first,
+                               (int)count, points_dev, b->stream);
+    HIP_TRY(hipGetLastError());
+    return store_and_linearise(b, points_dev, first, count);
 }
 
 int nmpc_batch_preparation_step(nmpc_batch_t* b) {

@@ -1,0 +1,79 @@
+"""GPU test of nmpc_batch_set_reference_from_waypoints_noalloc, the entry point
+for callers that cannot allocate device memory: called through the C ABI
+(ctypes), its results must be bit-identical to those of
+nmpc_batch_set_reference_from_waypoints, on two calls in a row that share the
+library's fixed scratch array, the second with a smaller input."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _waypoints(B, rng, end=0.9):
+    from nmpc_amd import synthetic as S
+    wp14 = S.waypoint_batch(B, rng, turn_start=(0.1, 0.6), turn_time=0.5)
+    wp = np.concatenate([wp14, np.full((B, wp14.shape[1], 3), 0.5)], axis=-1)
+    wp[:, -1, 0] = end
+    return np.ascontiguousarray(wp)
+
+
+def _run(B, N, wp, wind, meas, t0, dt, noalloc, pieces):
+    """Cold start from waypoints, one feedback step; -> controls, stage records
+    and solver state of three instances."""
+    import torch
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    dev = torch.device("cuda:0")
+    bt = Batch(B, N, stream=torch.cuda.current_stream(dev).cuda_stream)
+    bt.setup(**S.setup_args())
+    bt.initialise_horizon()
+    bt.set_wind_velocity(wind)
+    wpd = torch.from_numpy(wp).to(dev)
+    load = bt.set_reference_from_waypoints_noalloc if noalloc else bt.set_reference_from_waypoints
+    for first, count in pieces:
+        load(wpd, t0, dt, first, count)
+    bt.solve(meas)
+    out = bt.get_controls()
+    picks = sorted({0, B // 2, B - 1})
+    st = [bt.stages(b) for b in picks]
+    gl = [bt.globals_(b) for b in picks]
+    bt.close()
+    return out, st, gl
+
+
+def test_no_alloc_entry_point_matches_the_allocating_one():
+    from helpers import assert_same
+    from nmpc_amd import _lib
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    import torch
+
+    dt, t0 = 1.0 / 50.0, 0.013
+    # first call: 600 x 101 = 60 600 points, close to the 65 536 the scratch holds;
+    # second call: a smaller batch, a shorter horizon, loaded in two pieces
+    for B, N, pieces, seed in ((600, 100, ((0, 101),), 41), (37, 30, ((0, 11), (11, 20)), 42)):
+        rng = np.random.default_rng(seed)
+        wp = _waypoints(B, rng)
+        d = S.make_batch(B, N, seed=seed)
+        meas = np.ascontiguousarray(wp[:, 0, 1:14]) + 0.01      # near the first reference point
+        ref = _run(B, N, wp, d["wind"], meas, t0, dt, False, pieces)
+        got = _run(B, N, wp, d["wind"], meas, t0, dt, True, pieces)
+        for a, b, what in zip(ref[0], got[0], ("controls", "status", "iterations")):
+            assert_same(b, a, "B=%d %s" % (B, what))
+        for i in range(len(ref[1])):
+            assert_same(got[1][i], ref[1][i], "B=%d stage records %d" % (B, i))
+            assert_same(got[2][i], ref[2][i], "B=%d solver state %d" % (B, i))
+        assert (ref[0][1] == 0).any()       # the solves did something
+
+    # beyond the fixed scratch, and host waypoints: clear errors, nothing launched
+    bt = Batch(700, 100)
+    bt.setup(**S.setup_args())
+    bt.initialise_horizon()
+    wp = torch.from_numpy(_waypoints(700, np.random.default_rng(1))).to("cuda:0")
+    with pytest.raises(_lib.NmpcError, match="exceed the fixed scratch"):
+        bt.set_reference_from_waypoints_noalloc(wp, t0, dt)
+    with pytest.raises(_lib.NmpcError, match="device memory"):
+        bt.set_reference_from_waypoints_noalloc(wp.cpu().numpy(), t0, dt, 0, 5)
+    bt.set_reference_from_waypoints_noalloc(wp, t0, dt, 0, 90)     # 63 000 points: accepted
+    bt.synchronize()
+    bt.close()
