@@ -122,7 +122,11 @@ def main():
     out_st = torch.zeros(B, dtype=torch.int32, device=dev)
     out_it = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    stream = torch.cuda.current_stream(dev)
+    # one explicit stream for the batch's kernels, torch's copies and the timing
+    # events (torch's default stream has handle 0, which Batch() reads as "make
+    # a private stream")
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     bt = Batch(B, N, device=local, stream=stream.cuda_stream)
     bt.setup(**S.setup_args())
 
