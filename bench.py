@@ -1,13 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the batched NMPC hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--instances B] [--horizon H]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,4,5}]
+                    [--instances B] [--horizon H]
 
-One step = one cold solve of a batch of B independent controllers, i.e. the
-reference's start-up sequence per controller (state reset, nmpc_init, wind,
-H+1 reference points -- which runs the RK4 + finite-difference linearisation
-of every horizon stage -- one feedback step, get controls), with all inputs
-already resident in HBM.  Default workload: 4096 instances, horizon 100, fp64.
+--config selects the workload (the numbered configurations of the reference
+benchmark definition):
+
+  2 (default)  B = 4096 independent controllers, horizon 100.  One step = one
+               cold solve of the batch: the reference's start-up sequence per
+               controller (state reset, nmpc_init, wind, H+1 reference points
+               -- which runs the RK4 + finite-difference linearisation of every
+               horizon stage -- one feedback step, get controls), all inputs
+               resident in HBM.  --instances 32768 is the per-GPU share of the
+               262 144-instance, 8-GPU configuration.
+  4            the same step for 1024 controllers with a 500-stage horizon.
+  5            2^20 independent (x, u, wind) samples through the stage
+               linearisation only (16 RK4 integrations + Jacobian per sample).
+  1            one controller through the reference's 24-symbol interface:
+               latency of the 50 Hz control step, beside the CPU on one core.
+
 With --gpus N > 1 (launched through torch.distributed.run) every rank owns B
 instances on its own GPU (weak scaling) and the per-step results are
 all-gathered over RCCL.
@@ -15,12 +27,16 @@ all-gathered over RCCL.
 Prints one JSON line on rank 0.  Besides the whole-job rate it carries
   roofline      the dominant kernel's algorithmic HBM bytes per launch over its
                 mean launch duration, measured with HIP events on the stream
-                the kernels run on, during the timed steps
+                the kernels run on, during the timed steps; next to the vendor
+                peaks the peaks measured in the same run (stream triad, fp64
+                vector rate with and without fused multiply-add)
   cpu_baseline  the CPU oracle port (oracle/nmpc_port.c, a restatement of the
-                reference's pure-C path, bit-identical to it) on the same
-                inputs, threaded over the host cores of this box.
+                reference's pure-C path, bit-identical to it) or, for config 1,
+                the compiled reference itself where it is present, on the same
+                inputs on the host cores of this box.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -32,11 +48,13 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (before libcnmpc.so: see nmpc_amd/_lib.py)
 
+from nmpc_amd import _lib  # noqa: E402
 from nmpc_amd import synthetic as S  # noqa: E402
 from nmpc_amd.batch import Batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector, spec (FMA counted as 2 flop)
+METRIC = "NMPC solves/sec (prep+feedback) at batch B, default horizon"
 
 # Algorithmic work per unit, from the operation counts of the reference
 # functions (one flop per add/sub/mul/div/sqrt/compare-select):
@@ -65,53 +83,89 @@ ALGO = {
     "newton_step": dict(flop=670.0, bytes=3100.0),
     "qp_begin": dict(flop=260.0, bytes=1100.0),
 }
+# what limits each kernel: linearise sits at the fp64-vector / HBM ridge and is
+# instruction-bound; the Newton solve is a dependent chain per instance,
+# HBM-bound only while every block is factorised
+BOUND = {"linearise": "fp64-vector", "newton_solve": "issue-latency", "qp_begin": "hbm",
+         "newton_step": "hbm"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--instances", type=int, default=4096, help="controller instances per GPU")
-    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 4, 5))
+    ap.add_argument("--instances", type=int, default=None, help="controller instances per GPU")
+    ap.add_argument("--horizon", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=1 << 20, help="config 5: samples per GPU")
     ap.add_argument("--seed", type=int, default=S.DEFAULT_SEED)
     ap.add_argument("--warm-steps", type=int, default=20,
                     help="warm control steps timed after the cold solves (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4096,
-                    help="instances of the workload the CPU baseline solves")
-    return ap.parse_args()
+    ap.add_argument("--no-peaks", action="store_true", help="skip the peak microbenchmarks")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="units of the workload the CPU baseline processes per pass")
+    a = ap.parse_args()
+    if a.instances is None:
+        a.instances = {1: 1, 2: 4096, 4: 1024, 5: 0}[a.config]
+    if a.horizon is None:
+        a.horizon = 500 if a.config == 4 else 100
+    if a.steps is None:
+        a.steps = {1: 200, 2: 20, 4: 10, 5: 20}[a.config]
+    return a
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                     % (a.gpus, a.gpus))
-        a.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
-    # Rehearsal of the multi-rank path on a box with fewer GPUs than ranks:
-    # NMPC_BENCH_REHEARSE=1 lets ranks share GPUs and gathers over gloo (RCCL
-    # refuses two ranks on one device).  Never set for a measurement.
-    rehearse = os.environ.get("NMPC_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+def percentile(sorted_ms, q):
+    return sorted_ms[min(len(sorted_ms) - 1, int(q * len(sorted_ms)))]
 
+
+def measure_peaks(device):
+    """Stream triad and fp64 vector rates of this GPU, measured now."""
+    lib = _lib.load()
+    out = {}
+    v = C.c_double()
+    if lib.nmpc_measure_stream_triad(device, 1 << 30, C.byref(v)) == 0:
+        out["hbm_triad_GBps"] = round(v.value, 1)
+    if lib.nmpc_measure_fp64_vector_peak(device, 0, C.byref(v)) == 0:
+        out["fp64_vector_no_fma_TFLOPs"] = round(v.value, 2)
+    if lib.nmpc_measure_fp64_vector_peak(device, 1, C.byref(v)) == 0:
+        out["fp64_vector_fma_TFLOPs"] = round(v.value, 2)
+    return out
+
+
+def load_traffic(tag, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this
+    workload (tools/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % tag)
+    if os.path.exists(path):
+        return json.load(open(path)).get("bytes_per_launch", {}).get(kernel)
+    return None
+
+
+def make_roofline(kernel, kern, algo_bytes, peaks, traffic):
+    k = kern[kernel]
+    achieved = k["algo_GBps"]
+    r = dict(kernel=kernel, bound=BOUND.get(kernel, "hbm"), achieved=achieved, peak=HBM_PEAK_GBS,
+             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+             avg_launch_ms=k["avg_ms"],
+             algo_bytes_per_launch=round(algo_bytes[kernel] / max(1, k["launches"])),
+             fp64_vector_TFLOPs=k["algo_TFLOPs"],
+             fp64_vector_frac=round(k["algo_TFLOPs"] / FP64_VECTOR_PEAK_TF, 5))
+    if peaks:
+        r["peak_measured"] = peaks
+        if peaks.get("hbm_triad_GBps"):
+            r["frac_of_measured_hbm"] = round(achieved / peaks["hbm_triad_GBps"], 5)
+        if peaks.get("fp64_vector_no_fma_TFLOPs"):
+            r["frac_of_measured_fp64_no_fma"] = round(
+                k["algo_TFLOPs"] / peaks["fp64_vector_no_fma_TFLOPs"], 5)
+    return r
+
+
+# ---------------------------------------------------------------------------
+# configs 2 and 4: cold solve of a batch
+# ---------------------------------------------------------------------------
+def run_cold(a, world, rank, local, dev, dist, peaks):
     B, N = a.instances, a.horizon
     # every rank draws its own instances: seed + rank
     d = S.make_batch(B, N, seed=a.seed + rank)
@@ -150,7 +204,7 @@ def main():
     # warm-up steps (all kernels timed there).  The per-kernel table comes from a
     # short pass after the timed region.
     bt.set_profiling(True)
-    for _ in range(a.warmup):
+    for _ in range(max(1, a.warmup)):
         step()
     torch.cuda.synchronize(dev)
     pre = {k: ms for k, (ms, n) in bt.kernel_times().items() if n and k in ALGO}
@@ -186,6 +240,7 @@ def main():
             step()
         ktable = bt.kernel_times()
         bt.set_profiling(False)
+    torch.cuda.synchronize(dev)
     u_all, st_all, it_all = (x.cpu().numpy() for x in res)
     u, st, it = out_u.cpu().numpy(), out_st.cpu().numpy(), out_it.cpu().numpy()
 
@@ -199,23 +254,25 @@ def main():
     warm = None
     if world == 1 and a.warm_steps > 0:
         dw = S.make_batch(B, N, extra_steps=a.warm_steps, seed=a.seed + rank)
-        wrefs = torch.from_numpy(np.ascontiguousarray(dw["refs"][:, N + 1:])).to(dev)
-        wmeas = torch.from_numpy(np.ascontiguousarray(dw["meas"][:, 1:])).to(dev)
+        wrefs = torch.from_numpy(np.ascontiguousarray(
+            dw["refs"][:, N + 1:].transpose(1, 0, 2))).to(dev)      # [step][B][16]
+        wmeas = torch.from_numpy(np.ascontiguousarray(
+            dw["meas"][:, 1:].transpose(1, 0, 2))).to(dev)          # [step][B][13]
         wm = [torch.cuda.Event(enable_timing=True) for _ in range(a.warm_steps + 1)]
-        bt.update_horizon(wrefs[:, 0].contiguous())
+        bt.update_horizon(wrefs[0])
         torch.cuda.synchronize(dev)
         wm[0].record(stream)
         for k in range(a.warm_steps):
             bt.prepare()
-            bt.solve(wmeas[:, k].contiguous())
+            bt.solve(wmeas[k])
             bt.get_controls_into(out_u, out_st, out_it)
             if k + 1 < a.warm_steps:
-                bt.update_horizon(wrefs[:, k + 1].contiguous())
+                bt.update_horizon(wrefs[k + 1])
             wm[k + 1].record(stream)
         torch.cuda.synchronize(dev)
         wms = sorted(wm[k].elapsed_time(wm[k + 1]) for k in range(a.warm_steps))
-        warm = dict(steps=a.warm_steps, p50_ms=round(wms[len(wms) // 2], 4),
-                    p99_ms=round(wms[min(len(wms) - 1, int(0.99 * len(wms)))], 4),
+        warm = dict(steps=a.warm_steps, p50_ms=round(percentile(wms, 0.5), 4),
+                    p99_ms=round(percentile(wms, 0.99), 4),
                     steps_per_s=round(B * a.warm_steps / (sum(wms) / 1e3), 1),
                     ok_frac=round(float((out_st.cpu().numpy() == 0).mean()), 4))
 
@@ -223,6 +280,7 @@ def main():
     # units each launch kind processed over the timed steps
     newton_runs = np.where(st == 0, it - 1, it).astype(np.int64)    # factor/step executions
     setup_runs = it.astype(np.int64)                                # gradient evaluations
+
     # algorithmic bytes / flop each kernel kind processed over the timed steps; the Newton
     # set-up runs fused behind qp_begin (iteration 1) and newton_step (later iterations)
     def rates(times, steps):
@@ -258,19 +316,13 @@ def main():
         dominant = max(algo_bytes, key=lambda k: timed_kern[k]["total_ms"])
     kern = rates(ktable, table_steps)[0] if table_steps else timed_kern
     kern[dominant] = timed_kern[dominant]
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("instances") == B and tj.get("horizon") == N:
-            traffic = tj.get("bytes_per_launch", {}).get(dominant)
-    achieved = kern[dominant]["algo_GBps"]
-    roofline = dict(kernel=dominant, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                    avg_launch_ms=kern[dominant]["avg_ms"],
-                    algo_bytes_per_launch=round(algo_bytes[dominant]
-                                                / max(1, kern[dominant]["launches"])),
-                    fp64_vector_frac=round(kern[dominant]["algo_TFLOPs"] / FP64_VECTOR_PEAK_TF, 5))
+    tag = "cfg%d" % a.config if (B, N) in ((4096, 100), (1024, 500)) else "b%d_n%d" % (B, N)
+    roofline = make_roofline(dominant, kern, algo_bytes, peaks, load_traffic(tag, dominant))
+    # the stage linearisation beside it, whichever kernel dominates
+    if "linearise" in kern and dominant != "linearise":
+        lin_bytes = {"linearise": ALGO["linearise"]["bytes"] * B * N * kern["linearise"]["launches"]}
+        roofline["linearise"] = make_roofline("linearise", kern, lin_bytes, None,
+                                              load_traffic(tag, "linearise"))
 
     # ---- CPU baseline (rank 0, N=1 only) -------------------------------------
     cpu = None
@@ -278,7 +330,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import portdriver as P
         cores = max(1, min(16, len(os.sched_getaffinity(0))))
-        n = min(a.cpu_sample, B)
+        n = min(a.cpu_sample or 4096, B)
         cfg = S.setup_args()
         # repeat the sample until about 1.5 s of wall time (~20 core-seconds) has been timed
         secs, passes = 0.0, 0
@@ -296,19 +348,22 @@ def main():
                           "%.2f s wall on %d threads" % (n, passes, secs, cores),
                    gpu_results_identical=parity)
 
+    line = None
     if rank == 0:
         line = {
-            "metric": "NMPC solves/sec (prep+feedback) at batch B, default horizon",
+            "metric": METRIC,
             "value": round(value, 1), "unit": "solves/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-            "p50_step_ms": round(step_ms[len(step_ms) // 2], 4),
+            "p50_step_ms": round(percentile(step_ms, 0.5), 4),
+            "p99_step_ms": round(percentile(step_ms, 0.99), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d independent UAV NMPC instances per GPU, horizon %d, "
                                    "cold solve (reset, init, %d reference points = all stages "
                                    "linearised, feedback, get controls), fp64"
                                    % (B, N, N + 1),
+                       "baseline_config": a.config,
                        "instances_per_gpu": B, "horizon": N, "total_instances": total_instances,
                        "parallelism": "instance partition, %d GPU(s)" % world},
             "roofline": roofline,
@@ -321,8 +376,249 @@ def main():
             "solver": {"converged_frac": round(float((st_all == 0).mean()), 4),
                        "mean_qp_iterations": round(float(it_all.mean()), 3)},
         }
-        print(json.dumps(line))
     bt.close()
+    return line
+
+
+# ---------------------------------------------------------------------------
+# config 5: stage linearisation of independent samples
+# ---------------------------------------------------------------------------
+def run_samples(a, world, rank, local, dev, dist, peaks):
+    n = a.samples
+    rng = np.random.default_rng(a.seed + rank)
+    x, u, w = S.random_states(n, rng)
+    xn = np.roll(x, 1, axis=0)
+    lo, up = np.zeros(3), np.ones(3)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    tx, tu, tn, tw = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, u, xn, w))
+    jac = torch.empty((n, 180), dtype=torch.float64, device=dev)
+    res = torch.empty((n, 12), dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    plo, pup = lo.ctypes.data_as(_lib.PREAL), up.ctypes.data_as(_lib.PREAL)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    hs = C.c_void_p(stream.cuda_stream)
+
+    def step():
+        _lib.check(lib, lib.nmpc_linearise_samples(local, hs, n, ptr(tx), ptr(tu), ptr(tn), ptr(tw),
+                                                   plo, pup, ptr(jac), ptr(res)))
+
+    for _ in range(max(1, a.warmup)):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record(stream)
+    for k in range(a.steps):
+        step()
+        marks[k + 1].record(stream)     # each step is one launch: these are launch durations
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
+    avg_ms = sum(step_ms) / len(step_ms)
+    al = ALGO["linearise"]
+    kern = {"linearise": dict(total_ms=round(sum(step_ms), 3), launches=a.steps,
+                              avg_ms=round(avg_ms, 4),
+                              algo_GBps=round(al["bytes"] * n / 1e9 / (avg_ms / 1e3), 1),
+                              algo_TFLOPs=round(al["flop"] * n / 1e12 / (avg_ms / 1e3), 3))}
+    roofline = make_roofline("linearise", kern, {"linearise": al["bytes"] * n * a.steps}, peaks,
+                             load_traffic("cfg5", "linearise_free"))
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import portdriver as P
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        m = min(a.cpu_sample or (1 << 18), n)
+        secs, passes = 0.0, 0
+        while secs < 1.5 and passes < 16:
+            cj, cr, s1 = P.batch_linearise(x[:m], u[:m], xn[:m], w[:m], lo, up, threads=cores)
+            secs += s1
+            passes += 1
+        gj, gr = jac[:m].cpu().numpy(), res[:m].cpu().numpy()
+        cpu = dict(value=round(m * passes / secs, 1), unit="stage linearisations/s", cores=cores,
+                   kind="port",
+                   sample="first %d samples of the same workload, %d passes, %.2f s wall on %d "
+                          "threads" % (m, passes, secs, cores),
+                   gpu_results_identical=bool(np.array_equal(cj, gj) and np.array_equal(cr, gr)))
+    if rank != 0:
+        return None
+    return {
+        "metric": "stage linearisations/sec (RK4 + finite-difference Jacobian per sample)",
+        "value": round(n * world * a.steps / elapsed, 1), "unit": "stage linearisations/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+        "p50_step_ms": round(percentile(step_ms, 0.5), 4),
+        "p99_step_ms": round(percentile(step_ms, 0.99), 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%d independent (x, u, wind) samples per GPU through the stage "
+                               "linearisation (1 nominal + 15 perturbed RK4 integrations, "
+                               "12x15 Jacobian and residual out), fp64" % n,
+                   "baseline_config": 5, "samples_per_gpu": n,
+                   "parallelism": "sample partition, %d GPU(s)" % world},
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+    }
+
+
+# ---------------------------------------------------------------------------
+# config 1: one controller through the reference's own interface
+# ---------------------------------------------------------------------------
+def run_single(a, local, dev, peaks):
+    os.environ["NMPC_DEVICE"] = str(local)
+    import nmpc_amd as nmpc
+    N = 100
+    steps = a.steps
+    d = S.make_batch(1, N, extra_steps=steps + a.warmup + 1, seed=a.seed)
+    refs, meas, wind = d["refs"][0], d["meas"][0], d["wind"][0]
+    cfg = S.setup_args()
+    nmpc.init()
+    nmpc.setup(**{k: list(v) for k, v in cfg.items()})
+    t0 = time.perf_counter()
+    nmpc.initialise_horizon()
+    nmpc.set_wind_velocity(list(wind))
+    for i in range(N + 1):
+        nmpc.set_reference(list(refs[i]), i)
+    nmpc.prepare()
+    nmpc.solve(list(meas[0]))
+    u0 = nmpc.get_controls()
+    cold_ms = (time.perf_counter() - t0) * 1e3
+
+    def control_step(k):
+        nmpc.update_horizon(list(refs[N + 1 + k]))
+        nmpc.prepare()
+        nmpc.set_wind_velocity(list(wind))
+        nmpc.solve(list(meas[k + 1]))
+        return nmpc.get_result()
+
+    for k in range(a.warmup):
+        control_step(k)
+    lat, us, sts = [], [], []
+    tstart = time.perf_counter()
+    for k in range(a.warmup, a.warmup + steps):
+        t1 = time.perf_counter()
+        uk, stk = control_step(k)
+        lat.append((time.perf_counter() - t1) * 1e3)
+        us.append(uk)
+        sts.append(stk)
+    elapsed = time.perf_counter() - tstart
+    lat.sort()
+
+    # the same loop on one host core: the compiled reference where it travelled
+    # with the tree, otherwise the oracle port
+    cpu = None
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        kind = "port"
+        ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_n100.so")
+        if os.path.exists(ref_so):
+            import refdriver
+            drv = refdriver.Ref(100)
+            kind = "reference"
+        else:
+            import portdriver
+            drv = portdriver.Port(100)
+        drv.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                  cfg["upper_control_bound"], cfg["lower_control_bound"])
+        drv.init()
+        drv.set_wind(wind)
+        for i in range(N + 1):
+            drv.set_reference(refs[i], i)
+        drv.feedback(meas[0])
+        cu0, _ = drv.controls()
+        clat, same = [], bool(np.array_equal(np.asarray(cu0), np.asarray(u0)))
+        for k in range(a.warmup + steps):
+            t1 = time.perf_counter()
+            drv.update_horizon(refs[N + 1 + k])
+            drv.set_wind(wind)
+            drv.feedback(meas[k + 1])
+            cu, cst = drv.controls()
+            if k >= a.warmup:
+                clat.append((time.perf_counter() - t1) * 1e3)
+                j = k - a.warmup
+                same = same and bool(np.array_equal(np.asarray(cu), np.asarray(us[j]))
+                                     and cst == sts[j])
+        clat.sort()
+        cpu = dict(value=round(1e3 * len(clat) / sum(clat), 1), unit="solves/s", cores=1, kind=kind,
+                   p50_ms=round(percentile(clat, 0.5), 4), p99_ms=round(percentile(clat, 0.99), 4),
+                   sample="the same %d control steps of the same controller, one thread, "
+                          "through ctypes" % len(clat),
+                   gpu_results_identical=same)
+    return {
+        "metric": METRIC, "value": round(steps / elapsed, 1), "unit": "solves/s", "n_gpus": 1,
+        "steps": steps, "warmup": a.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "p50_step_ms": round(percentile(lat, 0.5), 4), "p99_step_ms": round(percentile(lat, 0.99), 4),
+        "cold_start_ms": round(cold_ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "one UAV NMPC controller, horizon 100, through the reference's "
+                               "24-symbol C interface (Python module mirror): control step = "
+                               "update_horizon, prepare, set wind, feedback, get controls; host "
+                               "wall time per step, fp64",
+                   "baseline_config": 1, "instances_per_gpu": 1, "horizon": N},
+        "roofline": dict(kernel="whole control step", bound="launch-latency", achieved=None,
+                         peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
+                         note="one instance keeps one workgroup busy; the step is a fixed "
+                              "sequence of dependent launches, not a bandwidth or flop question",
+                         peak_measured=peaks),
+        "cpu_baseline": cpu,
+        "solver": {"converged_frac": round(float(np.mean([s == 0 for s in sts])), 4)},
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                     % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    # Rehearsal of the multi-rank path on a box with fewer GPUs than ranks:
+    # NMPC_BENCH_REHEARSE=1 lets ranks share GPUs and gathers over gloo (RCCL
+    # refuses two ranks on one device).  Never set for a measurement.
+    rehearse = os.environ.get("NMPC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    peaks = None
+    if rank == 0 and not a.no_peaks:
+        peaks = measure_peaks(local)
+    if dist:
+        dist.barrier()
+
+    if a.config == 1:
+        if world > 1:
+            sys.exit("config 1 is a single controller: run it with --gpus 1")
+        line = run_single(a, local, dev, peaks)
+    elif a.config == 5:
+        line = run_samples(a, world, rank, local, dev, dist, peaks)
+    else:
+        line = run_cold(a, world, rank, local, dev, dist, peaks)
+    if rank == 0:
+        print(json.dumps(line))
     if dist:
         dist.destroy_process_group()
 

@@ -265,6 +265,18 @@ int nmpc_linearise_samples(int device, void *stream, uint64_t n, const real_t *x
 int nmpc_rk4_samples(int device, void *stream, uint64_t n, const real_t *x,
                      const real_t *u, const real_t *wind, real_t delta, real_t *out);
 
+/* Measured machine peaks for roofline fractions (no counterpart in the
+ * reference; not on the controller path).  Each call allocates its own
+ * buffers, runs a few passes on the device's null stream and reports the
+ * last (vector rate) or best (triad) pass.
+ * fp64 vector rate: independent x <- x * a + b chains, 8 wavefronts per SIMD;
+ * fused != 0 uses one fused multiply-add per step (2 flop), fused == 0 a
+ * multiply and an add (the library's own kernels are built without
+ * contraction).  Stream triad: a[i] = b[i] + s * c[i] over three arrays of
+ * bytes_per_array each, 16 bytes per lane and access; reports 3 x bytes / time. */
+int nmpc_measure_fp64_vector_peak(int device, int fused, double *tflops);
+int nmpc_measure_stream_triad(int device, uint64_t bytes_per_array, double *gbps);
+
 #ifdef __cplusplus
 }
 #endif

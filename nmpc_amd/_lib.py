@@ -105,6 +105,8 @@ PROTOTYPES = {
                                [C.c_void_p] * 4 + [PREAL, PREAL] + [C.c_void_p] * 2),
     "nmpc_rk4_samples": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64] + [C.c_void_p] * 3 +
                          [REAL, C.c_void_p]),
+    "nmpc_measure_fp64_vector_peak": (C.c_int, [C.c_int, C.c_int, PREAL]),
+    "nmpc_measure_stream_triad": (C.c_int, [C.c_int, C.c_uint64, PREAL]),
 }
 
 _lib = None

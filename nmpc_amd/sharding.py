@@ -40,13 +40,16 @@ def gather_results(controls, status, iterations, group=None, counts=None):
     if counts is None:
         counts = gather_counts(controls.shape[0], controls.device, group)
     m = max(counts)
-    # one packed f64 record per instance: u0 u1 u2 status iterations
-    rec = torch.zeros((m, 5), dtype=torch.float64, device=controls.device)
+    # one packed 32-byte record per instance: u0 u1 u2 (f64), status, iterations (i32)
+    rec = torch.zeros((m, 4), dtype=torch.float64, device=controls.device)
     b = controls.shape[0]
     rec[:b, 0:3] = controls
-    rec[:b, 3] = status.to(torch.float64)
-    rec[:b, 4] = iterations.to(torch.float64)
-    parts = [torch.empty_like(rec) for _ in range(world)]
-    dist.all_gather(parts, rec, group=group)
-    full = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
-    return (full[:, 0:3].contiguous(), full[:, 3].to(torch.int32), full[:, 4].to(torch.int32))
+    tail = rec.view(torch.int32)        # [m][8]: words 6 and 7 are the fourth double
+    tail[:b, 6] = status
+    tail[:b, 7] = iterations
+    full = torch.empty((world * m, 4), dtype=torch.float64, device=controls.device)
+    dist.all_gather_into_tensor(full, rec, group=group)
+    if any(c != m for c in counts):
+        full = torch.cat([full[r * m:r * m + c] for r, c in enumerate(counts)], dim=0)
+    words = full.view(torch.int32)
+    return (full[:, 0:3].contiguous(), words[:, 6].contiguous(), words[:, 7].contiguous())

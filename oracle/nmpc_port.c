@@ -966,3 +966,39 @@ double port_batch_cold_solve(int horizon, int count, int threads,
     free(tid); free(jobs);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- batched stage linearisation (CPU baseline of the sample workload) ---- */
+typedef struct {
+    long first, last;
+    const double *x, *u, *xn, *w, *lo, *up;
+    double *jac, *res;
+} lin_job_t;
+
+static void *lin_worker(void *arg) {
+    const lin_job_t *j = (const lin_job_t *)arg;
+    for (long i = j->first; i < j->last; i++)
+        port_linearise(j->x + 13 * i, j->u + 3 * i, j->xn + 13 * i, j->w + 3 * i, j->lo, j->up,
+                       j->jac + 180 * i, j->res + 12 * i);
+    return 0;
+}
+
+double port_batch_linearise(long count, int threads, const double *x, const double *u,
+                            const double *xnext, const double *wind, const double *lower3,
+                            const double *upper3, double *jac, double *res) {
+    if (threads < 1) threads = 1;
+    if (threads > count) threads = (int)count;
+    pthread_t *tid = calloc((size_t)threads, sizeof(*tid));
+    lin_job_t *jobs = calloc((size_t)threads, sizeof(*jobs));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        lin_job_t j = {count * t / threads, count * (t + 1) / threads,
+                       x, u, xnext, wind, lower3, upper3, jac, res};
+        jobs[t] = j;
+        pthread_create(&tid[t], 0, lin_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], 0);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(tid); free(jobs);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

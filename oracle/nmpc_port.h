@@ -79,6 +79,12 @@ double port_batch_cold_solve(int horizon, int count, int threads,
                              const double *meas, const double *wind,
                              double *u, int *status, int *iters);
 
+/* port_linearise over `count` samples ([count][13], [count][3], ...) on `threads`
+ * host threads; returns wall seconds. */
+double port_batch_linearise(long count, int threads, const double *x, const double *u,
+                            const double *xnext, const double *wind, const double *lower3,
+                            const double *upper3, double *jac, double *res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ def lib():
         L.port_batch_cold_solve.restype = C.c_double
         L.port_batch_cold_solve.argtypes = (
             [C.c_int] * 3 + [dp] * 8 + [dp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        L.port_batch_linearise.restype = C.c_double
+        L.port_batch_linearise.argtypes = [C.c_long, C.c_int] + [dp] * 8
         _lib = L
     return _lib
 
@@ -184,3 +186,13 @@ def batch_cold_solve(horizon, wq, wr, wt, lower, upper, refs, meas, wind, thread
         _dp(_f(lower, 3)), _dp(_f(upper, 3)), _dp(refs), _dp(meas), _dp(wind),
         _dp(u), _ip(status), _ip(iters))
     return u, status, iters, secs
+
+
+def batch_linearise(x, u, xnext, wind, lower, upper, threads=1):
+    """[n][13], [n][3], [n][13], [n][3] -> (jac [n][180], res [n][12], seconds)"""
+    x, u, xnext, wind = _f(x), _f(u), _f(xnext), _f(wind)
+    n = x.shape[0]
+    jac, res = np.zeros((n, 180)), np.zeros((n, 12))
+    secs = lib().port_batch_linearise(n, threads, _dp(x), _dp(u), _dp(xnext), _dp(wind),
+                                      _dp(_f(lower, 3)), _dp(_f(upper, 3)), _dp(jac), _dp(res))
+    return jac, res, secs
