@@ -28,6 +28,7 @@ namespace {
 // Every lane of the wavefront stays active throughout, results of groups that
 // have nothing to do are computed and dropped.
 constexpr int kGroupsPerWave = 4;
+[[maybe_unused]] constexpr unsigned kOneWavePerSimd = 1024;   // 256 CUs x 4 SIMDs
 
 using Seq12 = std::make_integer_sequence<int, NX>;
 
@@ -253,11 +254,42 @@ NMPC_DEV void forward_columns(double (&xk)[NX], double& mine, double& sum,
     (forward_column<FAST, J>(xk, mine, sum, Ld, dd, t), ...);
 }
 
+// Row l of a block row (24 doubles, 192 bytes) into LDS at image + l * 1024 +
+// lane * 16.  The instruction offset moves both the global and the LDS
+// address, so the LDS base handed over makes up the difference.
+typedef __attribute__((address_space(3))) char* lds_bytes;
+template <int... Lrow>
+NMPC_DEV void fetch_rows_to_lds(const double* g0, lds_bytes image, std::integer_sequence<int, Lrow...>) {
+    (__builtin_amdgcn_global_load_lds(
+         (const __attribute__((address_space(1))) void*)g0,
+         (__attribute__((address_space(3))) void*)(image + Lrow * (1024 - 192)), 16, Lrow * 192, 0),
+     ...);
+}
+
+// Entry t of a 12-vector held in registers, t known only at run time.
+NMPC_DEV double L_diag(const double (&L)[NX], int t) {
+    double d = L[0];
+#pragma unroll
+    for (int l = 1; l < NX; l++) d = (t == l) ? L[l] : d;
+    return d;
+}
+
 // One sweep from block N-1 down to 0: blocks k <= start of an `active` group
 // are factorised (dual_qp.c:817-908), the others read their factor back; each
 // block then takes its step of the bottom-up substitution, which only needs
 // the factor rows just produced.  Returns ST_OK or ST_DIV_ZERO per group and
 // lowers minDiag to the smallest diagonal factor entry seen.
+// Block rows are fetched one iteration ahead, either into registers (STAGED
+// false) or straight into LDS with global_load_lds_dwordx4 (STAGED true): no
+// registers are held while the data is on its way, which brings the kernel
+// under 256 registers so that two wavefronts can share a SIMD; the price is a
+// wait for the LDS image at the top of every block, so batches that do not
+// fill the chip twice over keep the register form.
+// STAGED: lane t < 12 of a group brings in entries 2t and 2t+1 of each of the
+// twelve 24-entry rows, so the LDS image of row l is rows[l][group][24 of 32];
+// lane t then reads its column of the sub-diagonal block (entry t) and of the
+// diagonal block (entry 12 + t).
+template <bool STAGED>
 NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool active, int t,
                            double& minDiag) {
     const int N = v.N;
@@ -268,50 +300,75 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
 #pragma unroll
     for (int j = 0; j < NX; j++) { Ln[j] = 0.; pn[j] = 0.; xk[j] = 0.; }
 
-    // Block rows are fetched one iteration ahead.  When any group of the
-    // wavefront factorises a block, every group does, starting from the Newton
-    // Hessian: a block above a group's `start` has the same Hessian and the same
-    // factor below it as when it was last factorised (that is why the reference
-    // skips it), so the result is the factor it would have read back, and the
-    // columns need no per-lane choice between a computed and a fetched value.
-    // Groups whose results are dropped fetch nothing and work on zeros.
-    double nL[NX], nLs[NX], ng = 0., nd = 1.;
+    // When any group of the wavefront factorises a block, every group does,
+    // starting from the Newton Hessian: a block above a group's `start` has the
+    // same Hessian and the same factor below it as when it was last factorised
+    // (that is why the reference skips it), so the result is the factor it would
+    // have read back, and the columns need no per-lane choice between a computed
+    // and a fetched value.  Groups whose results are dropped fetch nothing and
+    // work on zeros.
+    __shared__ double rows[STAGED ? NX * kWave * 2 : 1];
+    const lds_bytes image = (lds_bytes)rows;
+    const int slot = (threadIdx.x >> 4) * 32;           // this group's part of a row image
+    double nL[STAGED ? 1 : NX], nLs[STAGED ? 1 : NX], ng = 0., nd = 1.;
+    if constexpr (STAGED) {
+        if (!active) {
 #pragma unroll
-    for (int l = 0; l < NX; l++) { nL[l] = 0.; nLs[l] = 0.; }
-    bool nextFromHess = __any(active && N - 1 <= start);
-    if (active) {
-        const double* src = nextFromHess ? I.hess : I.chol;
-#pragma unroll
-        for (int l = 0; l < NX; l++) {
-            nL[l] = HS(src, N - 1, 0, l, tc);
-            nLs[l] = HS(src, N - 1, -1, l, tc);
+            for (int l = 0; l < NX; l++) {
+                rows[l * 128 + 2 * threadIdx.x] = 0.;
+                rows[l * 128 + 2 * threadIdx.x + 1] = 0.;
+            }
         }
-        ng = I.grad[(N - 1) * NX + tc];
-        if (!nextFromHess) nd = HS(I.chol, N - 1, 0, tc, tc);
+    } else {
+#pragma unroll
+        for (int l = 0; l < NX; l++) { nL[l] = 0.; nLs[l] = 0.; }
     }
+    auto fetch_block_row = [&](bool fromH, int kk) {
+        const double* src = fromH ? I.hess : I.chol;
+        if constexpr (STAGED) {
+            const double* g0 = src + (size_t)kk * (2 * NX * NX) + 2 * tc;
+            if (active && col) fetch_rows_to_lds(g0, image, Seq12{});
+            if (active) ng = I.grad[kk * NX + tc];
+        } else if (active) {
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                nL[l] = HS(src, kk, 0, l, tc);
+                nLs[l] = HS(src, kk, -1, l, tc);
+            }
+            ng = I.grad[kk * NX + tc];
+            if (!fromH) nd = HS(I.chol, kk, 0, tc, tc);
+        }
+    };
+    bool nextFromHess = __any(active && N - 1 <= start);
+    fetch_block_row(nextFromHess, N - 1);
 
     for (int k = N - 1; k >= 0; --k) {
         const bool fromHess = nextFromHess;
         const bool factorThis = active && status == ST_OK && k <= start;
         double L[NX], Ls[NX];
+        double dd;                                      // chol(k,0,t,t) unless refactorised below
+        if constexpr (STAGED) {
+            // the block row fetched during the last iteration has landed ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int l = 0; l < NX; l++) { L[l] = nL[l]; Ls[l] = nLs[l]; }
+            for (int l = 0; l < NX; l++) {
+                Ls[l] = rows[l * 128 + slot + tc];
+                L[l] = rows[l * 128 + slot + NX + tc];
+            }
+            // ... and is in registers before the next one overwrites the image
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dd = (fromHess || !active) ? 1. : L_diag(L, tc);
+        } else {
+#pragma unroll
+            for (int l = 0; l < NX; l++) { L[l] = nL[l]; Ls[l] = nLs[l]; }
+            dd = nd;
+        }
         const double g = ng;
-        double dd = nd;                                // chol(k,0,t,t) unless refactorised below
         if (k > 0) {
             // a failure in this block is not known yet; a group that fails stops
             // using its results, so the guess "still factorising" is harmless
             nextFromHess = __any(active && status == ST_OK && k - 1 <= start);
-            if (active) {
-                const double* src = nextFromHess ? I.hess : I.chol;
-#pragma unroll
-                for (int l = 0; l < NX; l++) {
-                    nL[l] = HS(src, k - 1, 0, l, tc);
-                    nLs[l] = HS(src, k - 1, -1, l, tc);
-                }
-                ng = I.grad[(k - 1) * NX + tc];
-                if (!nextFromHess) nd = HS(I.chol, k - 1, 0, tc, tc);
-            }
+            fetch_block_row(nextFromHess, k - 1);
         }
         if (fromHess) {
             int failCol = -1;
@@ -415,7 +472,11 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 }  // namespace
 
 // dual_qp.c:601-698 followed by :993-1055
-__global__ __launch_bounds__(kWave) void k_newton_solve(BatchView v) {
+// WAVES = 1: one wavefront per SIMD, block rows prefetched into registers (more
+// than 256 of them).  WAVES = 2: two per SIMD, block rows staged through LDS.
+template <int WAVES>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void k_newton_solve(BatchView v) {
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
     const int bEnd = v.b0 + v.nb;
     const int bRaw = v.b0 + blockIdx.x * kGroupsPerWave + g;
@@ -434,7 +495,7 @@ __global__ __launch_bounds__(kWave) void k_newton_solve(BatchView v) {
     int from = start;
     for (int pass = 0; pass < 2; ++pass) {
         double minDiag = kInfty;
-        const int st = backward_pass(v, I, from, sweep, t, minDiag);
+        const int st = backward_pass<WAVES == 2>(v, I, from, sweep, t, minDiag);
         if (pass == 0) {
             minDiag = group_min(minDiag);
             const bool needReg = live && (st == ST_DIV_ZERO || minDiag < kDiagRegTol);
@@ -453,9 +514,20 @@ __global__ __launch_bounds__(kWave) void k_newton_solve(BatchView v) {
     forward_pass(v, I, live, t);
 }
 
+// Two wavefronts per SIMD only pay once there are wavefronts for it: the
+// dispatcher packs the workgroups of a grid onto CUs as densely as the
+// kernel's resources allow, so a grid of one wavefront per SIMD (1024 on this
+// chip) launched with the two-per-SIMD kernel leaves half of the SIMDs idle
+// (0.77 ms instead of 0.55 ms per launch at 4096 instances).
 void launch_newton_solve(const BatchView& v, hipStream_t s) {
     const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
-    hipLaunchKernelGGL(k_newton_solve, dim3(blocks), dim3(kWave), 0, s, v);
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds take the staged form at every size
+    const bool two = true;
+#else
+    const bool two = blocks > kOneWavePerSimd * 3 / 2;
+#endif
+    if (two) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
+    else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);
 }
 
 }  // namespace nmpc
