@@ -17,8 +17,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "kernels.hpp"
 #include "qp_common.hpp"
+
+// Minimum resident wavefronts per SIMD the stage linearisation is compiled for.
+// The stateless kernel fits three (165 registers).  The batch kernel also holds
+// the values its re-staging needs across the integration (178 registers): held
+// to three it spills them and is 9 % slower than at two.
+#ifndef NMPC_LINEARISE_WAVES
+#define NMPC_LINEARISE_WAVES 2
+#endif
+#ifndef NMPC_LINEARISE_FREE_WAVES
+#define NMPC_LINEARISE_FREE_WAVES 3
+#endif
 
 #pragma clang fp contract(off)
 
@@ -136,21 +149,40 @@ __global__ void k_init_stages(BatchView v, int part) {
 // point perturbed along column j (j == 15: unperturbed).  The nominal end state
 // is broadcast inside the group; lane j < 15 then owns column j of the 12x15
 // Jacobian, lane 15 owns the residual.
-NMPC_DEV void linearise_lane(const double* x0, const double* u0, const double* xnext,
-                             const double* wind, const double* lower,
-                             const double* upper, int j, double* out12) {
-    double x[NS], u[NU], moved[NS], nominal[NS];
+//
+// The kernel is bound by instruction issue, not by memory, so it is written to
+// keep registers low enough for three wavefronts per SIMD: lane i < 13 of a
+// group fetches entry i of the stage's state and of the next state (one
+// register pair each instead of 26 per lane; the 13 entries are one contiguous
+// 104-byte read per group), every lane collects the state through DPP row
+// broadcasts, and the next state is only unpacked once the integration is over.
+using Seq12 = std::make_integer_sequence<int, NX>;
+template <int... I>
+NMPC_DEV void gather_row(double (&out)[NS], double mine, std::integer_sequence<int, I...>) {
+    ((out[I] = row_bcast<I>(mine)), ...);
+}
+template <int... I>
+NMPC_DEV void bcast_from_last(double (&out)[NS], const double (&in)[NS],
+                              std::integer_sequence<int, I...>) {
+    ((out[I] = row_bcast<15>(in[I])), ...);
+}
+
+NMPC_DEV void linearise_lane(const double* xr, const double* xq, const double* ur,
+                             const double* wr, const double* lower, const double* upper,
+                             int j, double* out12) {
+    using Seq13 = std::make_integer_sequence<int, NS>;
+    const int li = j < NS ? j : 0;
+    const double mine = xr[li], mine_next = xq[li];
+    double x[NS], u[NU], wind[3], moved[NS], base[NS], next[NS];
+    gather_row(x, mine, Seq13{});
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = x0[i];
-#pragma unroll
-    for (int i = 0; i < NU; i++) u[i] = u0[i];
+    for (int i = 0; i < NU; i++) { u[i] = ur[i]; wind[i] = wr[i]; }
     const double hinv = perturb_point(x, u, j, lower, upper);
     rk4_step(moved, x, u, wind, kStepLength);
+    bcast_from_last(base, moved, Seq13{});              // nominal end state
+    gather_row(next, mine_next, Seq13{});               // (every lane of the row takes part)
 #pragma unroll
-    for (int i = 0; i < NS; i++) nominal[i] = __shfl(moved[i], 15, 16);
-    double base[NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) base[i] = (j == 15) ? xnext[i] : nominal[i];
+    for (int i = 0; i < NS; i++) base[i] = (j == 15) ? next[i] : base[i];
     state_to_delta(out12, base, moved);
     if (j < 15) {
 #pragma unroll
@@ -158,73 +190,83 @@ NMPC_DEV void linearise_lane(const double* x0, const double* u0, const double* x
     }
 }
 
-__global__ __launch_bounds__(256) void k_linearise(BatchView v, int first, int count) {
+template <int... I>
+NMPC_DEV double dot_with_row(const double (&col)[NX], double mine, std::integer_sequence<int, I...>) {
+    double acc = 0.;
+    ((acc += col[I] * row_bcast<I>(mine)), ...);
+    return acc;
+}
+
+// The multipliers, bounds and Hessian entry the re-staging needs are fetched
+// before the integration, one value per lane (a wavefront that asked for them
+// afterwards would sit out the memory latency with nothing left to do), and
+// the multiplier block is shared out by row broadcasts at the end.
+__global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchView v, int first, int count) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int j = (int)(gid & 15);
     long st = gid >> 4;
     const long total = (long)v.B * count;
     const bool live = st < total;
-    if (!live) st = total - 1;              // keep the whole group in the shuffles
+    if (!live) st = total - 1;              // keep the whole group in the broadcasts
     const int b = (int)(st / count), k = first + (int)(st % count);
-    Inst I = instance(v, b);
     const int s = stage_slot(v, k);
-
-    double x0[NS], xn[NS], u0[NU], w[3];
-    const double* xr = I.xref + (size_t)xref_slot(v, k) * NS;
-    const double* xq = I.xref + (size_t)xref_slot(v, k + 1) * NS;
+    const double* ur = v.uref + ((size_t)b * v.N + s) * NU;
+    // multipliers of the two coupling constraints this stage takes part in
+    const double* lam = v.lam + (size_t)b * v.N * NX;
+    const double lam_next = lam[(size_t)lam_slot(v, k) * NX + (j < NX ? j : 0)];
+    const bool has_prev = k > 0 && j < NX;
+    const double lam_prev = has_prev ? lam[(size_t)lam_slot(v, k - 1) * NX + j] : 0.;
+    double hj = v.H[0], lo = -kInfty, up = kInfty;
 #pragma unroll
-    for (int i = 0; i < NS; i++) { x0[i] = xr[i]; xn[i] = xq[i]; }
+    for (int i = 1; i < NZ; i++) hj = (i == j) ? v.H[i] : hj;
+    if (j >= NX && j < NZ) {
+        const double uj = ur[j - NX];
+        double lbj = 0.0, ubj = 0.0;
 #pragma unroll
-    for (int i = 0; i < NU; i++) { u0[i] = I.uref[s * NU + i]; w[i] = v.wind[(size_t)b * 3 + i]; }
-
+        for (int i = 0; i < NU; i++) {
+            lbj = (i == j - NX) ? v.lb[i] : lbj;
+            ubj = (i == j - NX) ? v.ub[i] : ubj;
+        }
+        lo = lbj - uj;
+        up = ubj - uj;
+    }
     double col[NX];
-    linearise_lane(x0, u0, xn, w, v.lb, v.ub, j, col);
+    {
+        const double* xref = v.xref + (size_t)b * (v.N + 1) * NS;
+        linearise_lane(xref + (size_t)xref_slot(v, k) * NS, xref + (size_t)xref_slot(v, k + 1) * NS,
+                       ur, v.wind + (size_t)b * 3, v.lb, v.ub, j, col);
+    }
+    // C' lambda_{k+1} (lanes j < 15) and c . lambda_{k+1} (lane 15): the same sum
+    const double dot = dot_with_row(col, lam_next, Seq12{});
     if (!live) return;
 
-    // multipliers of the two coupling constraints this stage takes part in
-    const double* l1 = I.lam + (size_t)lam_slot(v, k) * NX;
+    const size_t sb = (size_t)b, N = (size_t)v.N, N1 = N + 1;
     if (j < 15) {
-        double* Ck = I.C + (size_t)s * (NX * NZ);
+        double* Ck = v.C + (sb * N + s) * (NX * NZ);
 #pragma unroll
         for (int r = 0; r < NX; r++) Ck[r * NZ + j] = col[r];
-        double qs = 0.;
-#pragma unroll
-        for (int i = 0; i < NX; i++) qs += col[i] * l1[i];
-        if (k > 0 && j < NX) qs -= I.lam[(size_t)lam_slot(v, k - 1) * NX + j];
+        double qs = dot;
+        if (has_prev) qs -= lam_prev;
         qs = qs + 0.0;
-        const double d = qs / v.H[j];
-        I.qStep[s * NZ + j] = qs;
-        I.dz[s * NZ + j] = -d;
-        I.zUnc[s * NZ + j] = 0.0;
-        I.q[s * NZ + j] = 0.0;
-        double lo = -kInfty, up = kInfty;
-        if (j >= NX) {
-            double uj = 0.0, lbj = 0.0, ubj = 0.0;
-#pragma unroll
-            for (int i = 0; i < NU; i++) {
-                uj = (i == j - NX) ? u0[i] : uj;
-                lbj = (i == j - NX) ? v.lb[i] : lbj;
-                ubj = (i == j - NX) ? v.ub[i] : ubj;
-            }
-            lo = lbj - uj;
-            up = ubj - uj;
-        }
-        I.zLow[s * NZ + j] = lo;
-        I.zUpp[s * NZ + j] = up;
+        const double d = qs / hj;
+        const size_t e = (sb * N1 + s) * NZ + j;
+        v.qStep[e] = qs;
+        v.dz[e] = -d;
+        v.zUnc[e] = 0.0;
+        v.q[e] = 0.0;
+        v.zLow[e] = lo;
+        v.zUpp[e] = up;
     } else {
-        double ps = 0.;
+        double* cs = v.c + (sb * N + s) * NX;
 #pragma unroll
-        for (int i = 0; i < NX; i++) {
-            I.c[s * NX + i] = col[i];
-            ps += l1[i] * col[i];
-        }
-        I.pStep[s] = ps;
+        for (int i = 0; i < NX; i++) cs[i] = col[i];
+        v.pStep[sb * N1 + s] = dot;
     }
 }
 
 // Stateless variant: n samples, inputs [n][13] [n][3] [n][13] [n][3],
 // outputs jac [n][180] (row-major 12x15) and res [n][12].
-__global__ __launch_bounds__(256) void k_linearise_free(
+__global__ __launch_bounds__(256, NMPC_LINEARISE_FREE_WAVES) void k_linearise_free(
     long n, const double* __restrict__ xs, const double* __restrict__ us,
     const double* __restrict__ xnexts, const double* __restrict__ winds,
     Bounds bnd, double* __restrict__ jac, double* __restrict__ res) {
@@ -233,12 +275,8 @@ __global__ __launch_bounds__(256) void k_linearise_free(
     long st = gid >> 4;
     const bool live = st < n;
     if (!live) st = n - 1;
-    double x0[NS], xn[NS], u0[NU], w[3], col[NX];
-#pragma unroll
-    for (int i = 0; i < NS; i++) { x0[i] = xs[st * NS + i]; xn[i] = xnexts[st * NS + i]; }
-#pragma unroll
-    for (int i = 0; i < NU; i++) { u0[i] = us[st * NU + i]; w[i] = winds[st * 3 + i]; }
-    linearise_lane(x0, u0, xn, w, bnd.lb, bnd.ub, j, col);
+    double col[NX];
+    linearise_lane(xs + st * NS, xnexts + st * NS, us + st * NU, winds + st * 3, bnd.lb, bnd.ub, j, col);
     if (!live) return;
     if (j < 15) {
 #pragma unroll

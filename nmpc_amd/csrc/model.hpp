@@ -79,6 +79,38 @@ NMPC_DEV float approx_atan2(float y, float x) {
     return res;
 }
 
+// d = sqrt(x) and y = RN(1 / d) from one iteration.  The root is the compiler's
+// own expansion of sqrt (v_rsq_f64, one Goldschmidt step, two corrections)
+// without the rescaling it applies to x < 2^-767.  That iteration carries
+// h ~ 1 / (2 d) along; refined once more beside the corrections of the root,
+// it starts one Newton step and Markstein's correction, which give the
+// correctly rounded reciprocal of every d whose significand is not all ones.
+// Checked against sqrt, 1 / d and n / d on 2.6e10 random and adversarial
+// operands with exponents within +-400 on gfx950 (tools/micro_sqrt.hip): no
+// difference.  Callers keep x inside that range and handle the all-ones case.
+struct Pivot { double d, y; };
+NMPC_DEV Pivot root_and_reciprocal(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = r * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double e2 = __builtin_fma(-h, g, 0.5);
+    const double h2 = __builtin_fma(h, e2, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d1, h, g);
+    const double y0 = h2 + h2;
+    const double e0 = __builtin_fma(-g, y0, 1.0);
+    const double y1 = __builtin_fma(e0, y0, y0);
+    const double e1 = __builtin_fma(-g, y1, 1.0);
+    return {g, __builtin_fma(e1, y1, y1)};
+}
+NMPC_DEV bool significand_all_ones(double d) {
+    return (__double_as_longlong(d) & 0xfffffffffffffLL) == 0xfffffffffffffLL;
+}
+
 NMPC_DEV double sel_max(double a, double b) { return (a > b) ? a : b; }
 NMPC_DEV double sel_abs(double x) { return x < 0 ? -x : x; }
 
@@ -111,9 +143,27 @@ NMPC_DEV void x8_dynamics(double* out, const double* s, const double* u,
 
     double hv2 = ax2 + ay2;
     double qbar = (kRho * 0.5f) * hv2;
+#ifdef NMPC_FAST_ROOTS
+    // two roots and two divisions taken as two root-and-reciprocal iterations;
+    // operands outside the range that form is checked for (zero airflow among
+    // them) and roots with an all-ones significand take sqrt and / instead
+    const double s1 = sel_max(1.0f, hv2 + az2), s2 = ax2 + az2;
+    const Pivot p1 = root_and_reciprocal(s1), p2 = root_and_reciprocal(s2);
+    double v_inv = p1.y;
+    double vv = p2.d;
+    double vv_inv = (1.0f > vv) ? 1.0 : p2.y;
+    const bool checked = s1 <= 0x1p400 && s2 >= 0x1p-400 && s2 <= 0x1p400 &&
+                         !significand_all_ones(p1.d) && !significand_all_ones(p2.d);
+    if (__builtin_expect(!checked, 0)) {
+        v_inv = 1.0 / sqrt(s1);
+        vv = sqrt(s2);
+        vv_inv = 1.0 / sel_max(1.0f, vv);
+    }
+#else
     double v_inv = 1.0 / sqrt(sel_max(1.0f, hv2 + az2));
     double vv = sqrt(ax2 + az2);
     double vv_inv = 1.0 / sel_max(1.0f, vv);
+#endif
 
     double sin_b = af[1] * v_inv;
     double cos_b = vv * v_inv;

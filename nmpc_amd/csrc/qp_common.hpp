@@ -33,15 +33,19 @@ constexpr double kLsMaxStep = 1.;
 
 constexpr int kWave = 64;
 
-NMPC_DEV int stage_slot(const BatchView& v, int k) {
-    return k < v.N ? (v.head + k) % v.N : v.N;
+// Ring maps.  Offsets and positions are both below the ring length, so one
+// conditional subtraction takes the place of a remainder (an integer division
+// is some thirty instructions on this hardware).
+NMPC_DEV int ring_wrap(int x, int len) { return x >= len ? x - len : x; }
+NMPC_DEV int stage_slot(const BatchView& v, int k) {        // 0 <= k <= N
+    return k < v.N ? ring_wrap(v.head + k, v.N) : v.N;
 }
 // inverse of stage_slot
-NMPC_DEV int slot_position(const BatchView& v, int s) {
-    return s < v.N ? (s - v.head + v.N) % v.N : v.N;
+NMPC_DEV int slot_position(const BatchView& v, int s) {     // 0 <= s <= N
+    return s < v.N ? ring_wrap(s - v.head + v.N, v.N) : v.N;
 }
-NMPC_DEV int lam_slot(const BatchView& v, int k) { return (v.lhead + k) % v.N; }
-NMPC_DEV int xref_slot(const BatchView& v, int k) { return (v.xhead + k) % (v.N + 1); }
+NMPC_DEV int lam_slot(const BatchView& v, int k) { return ring_wrap(v.lhead + k, v.N); }       // 0 <= k < N
+NMPC_DEV int xref_slot(const BatchView& v, int k) { return ring_wrap(v.xhead + k, v.N + 1); }  // 0 <= k <= N
 
 // Per-instance base pointers.
 struct Inst {
@@ -102,6 +106,13 @@ NMPC_DEV double wave_min(double x) {
         x = y < x ? y : x;
     }
     return x;
+}
+
+// Value held by lane SRC of this lane's 16-lane DPP row (every lane of the row
+// must be active).
+template <int SRC>
+NMPC_DEV double row_bcast(double x) {
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, true);
 }
 
 NMPC_DEV double bcast_lane(double x, int src) {   // src must be wave-uniform

@@ -32,11 +32,6 @@ constexpr int kGroupsPerWave = 4;
 
 using Seq12 = std::make_integer_sequence<int, NX>;
 
-template <int SRC>
-NMPC_DEV double row_bcast(double x) {   // value held by lane SRC of this lane's group
-    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, true);
-}
-
 NMPC_DEV double group_min(double x) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
@@ -54,7 +49,6 @@ NMPC_DEV double group_min(double x) {
 // divisors whose significand is all ones; blocks that hold one use plain
 // division.  Checked against n / d on 2.6e10 random and adversarial operand
 // pairs on gfx950 (tools/micro_div.hip): no difference.
-struct Pivot { double d, y; };
 NMPC_DEV bool plain_division_needed(double d) {
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: the substitutions divide plainly too
     return true;
@@ -68,33 +62,6 @@ NMPC_DEV double divide(double n, const Pivot& p) {
     const double q0 = n * p.y;
     const double r = __builtin_fma(-p.d, q0, n);
     return __builtin_fma(r, p.y, q0);
-}
-
-// d = sqrt(x) and y = RN(1 / d) for a pivot x.  The root is the compiler's own
-// expansion of sqrt (v_rsq_f64, one Goldschmidt step, two corrections) without
-// the rescaling it applies to x < 2^-767, far below the smallest pivot the
-// factorisation accepts.  That iteration carries h ~ 1 / (2 d) along; refined once more
-// beside the corrections of the root, it starts one Newton step and Markstein's
-// correction, which give the correctly rounded reciprocal of every d whose
-// significand is not all ones.  Checked against sqrt, 1 / d and n / d on 2.6e10
-// random and adversarial operands on gfx950 (tools/micro_sqrt.hip): no difference.
-NMPC_DEV Pivot root_and_reciprocal(double x) {
-    const double r = __builtin_amdgcn_rsq(x);
-    double g = x * r, h = r * 0.5;
-    const double e = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
-    const double e2 = __builtin_fma(-h, g, 0.5);
-    const double h2 = __builtin_fma(h, e2, h);
-    const double d0 = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d0, h, g);
-    const double d1 = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d1, h, g);
-    const double y0 = h2 + h2;
-    const double e0 = __builtin_fma(-g, y0, 1.0);
-    const double y1 = __builtin_fma(e0, y0, y0);
-    const double e1 = __builtin_fma(-g, y1, 1.0);
-    return {g, __builtin_fma(e1, y1, y1)};
 }
 
 // Column JJ of block row k of the reverse Cholesky (dual_qp.c:832-903): pivot,
