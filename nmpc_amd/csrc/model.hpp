@@ -143,10 +143,11 @@ NMPC_DEV void x8_dynamics(double* out, const double* s, const double* u,
 
     double hv2 = ax2 + ay2;
     double qbar = (kRho * 0.5f) * hv2;
-#ifdef NMPC_FAST_ROOTS
-    // two roots and two divisions taken as two root-and-reciprocal iterations;
-    // operands outside the range that form is checked for (zero airflow among
-    // them) and roots with an all-ones significand take sqrt and / instead
+#ifndef NMPC_PLAIN_ROOTS
+    // two roots and two divisions taken as two root-and-reciprocal iterations
+    // (2 % of the stage linearisation); operands outside the range that form is
+    // checked for (zero airflow among them) and roots with an all-ones
+    // significand take sqrt and / instead
     const double s1 = sel_max(1.0f, hv2 + az2), s2 = ax2 + az2;
     const Pivot p1 = root_and_reciprocal(s1), p2 = root_and_reciprocal(s2);
     double v_inv = p1.y;
