@@ -461,6 +461,43 @@ NMPC_DEV void advance(Bisection& s, double slope, double normal) {
     settle(s);
 }
 
+// advance() for a trial whose two decisions are already known: `flat` =
+// |slope / normal| <= tolerance (the search ends there), `negative` = the slope
+// is below zero.  The slope's value itself never enters the search state.
+NMPC_DEV void advance_decided(Bisection& s, bool flat, bool negative) {
+    if (s.phase == 0) {
+        if (flat) { s.alpha = s.aMax; s.done = true; return; }
+        if (negative) { s.phase = 1; settle(s); return; }
+        s.aMin = s.aMax;
+        s.aMax *= kLsIncrease;
+        if (s.aMax > kLsMaxStep) { s.alpha = s.aMin; s.done = true; return; }
+        ++s.it;
+        if (s.it >= kMaxLsRefine) s.phase = 1;
+    } else {
+        s.aMid = 0.5 * (s.aMin + s.aMax);
+        if (flat) { s.alpha = s.aMid; s.done = true; return; }
+        if (negative) s.aMax = s.aMid; else s.aMin = s.aMid;
+        ++s.it;
+    }
+    settle(s);
+}
+
+// A slope is the sum of n terms added in row order, and the search only asks
+// two things of it: is |slope / normal| within the tolerance, and is it
+// negative.  Any order of summation lands within (n - 1) u sum|t| / (1 - (n - 1) u)
+// of the true sum, so a tree sum s and the magnitude sum m settle both
+// questions for the row-order sum too whenever |s| is further from the
+// threshold than twice that bound (taken generously, with room for the rounding
+// of m, of the threshold and of the quotient).  Otherwise the caller adds the
+// terms in order.
+NMPC_DEV bool slope_decided(double s, double m, int n, double normal, bool* flat, bool* negative) {
+    const double thr = kLsStatTol * normal;
+    const double slack = 4.0 * (double)n * 1.1102230246251565e-16 * m + 1e-12 * thr;
+    *flat = fabs(s) < thr;
+    *negative = s < 0.;
+    return fabs(fabs(s) - thr) > slack;         // false for NaN operands as well
+}
+
 // The state after a trial that did not end the search and whose slope was
 // negative / positive: advance() without the tests a real slope needs.
 NMPC_DEV void advance_assuming(Bisection& s, bool negative) {
@@ -657,7 +694,7 @@ constexpr int kTailMaxHorizon = 106;    // the tree's trial points and slope ter
 // Slope-term lists are accumulated side by side, one DPP row each; a stride that is
 // 5 mod 32 doubles keeps the rows on different LDS banks.
 NMPC_DEV int tail_term_stride(int n) { return n + ((5 - n % 32) + 32) % 32; }
-static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon + 32) * 8 + 128 <= 160 * 1024,
+static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon + 32) * 8 + 256 <= 160 * 1024,
               "trial points and slope terms must fit LDS");
 static_assert(NZ * (kTailMaxHorizon + 1) <= kTailElems * kTailThreads, "stage vectors must fit");
 static_assert(NX / 2 * kTailMaxHorizon <= kTailThreads, "two gradient rows per thread");
@@ -665,7 +702,7 @@ NMPC_DEV bool tail_capable(const BatchView& v) {
     return v.tailList != nullptr && v.N <= kTailMaxHorizon;
 }
 inline size_t tail_lds_bytes(int N) {
-    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(double) + 128;
+    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(double) + 256;
 }
 }  // namespace
 
@@ -843,6 +880,8 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
     const int ts = tail_term_stride(n);
     double* slopes = terms + kTailPoints * ts;              // [points]
     double* plan = slopes + 8;                              // [0] search over, [1..points] trial steps
+    double* mags = plan + 8;                                // [points] sums of the terms' magnitudes
+    double* redo = mags + 8;                                // [0] != 0: this round needs the row-order sums
     // gradient rows: thread t < 6 N owns rows h and h + 6 of block t / 6
     const int rk = tid / (NX / 2), rh = tid % (NX / 2);
     const bool rowOn = rk < N;
@@ -943,29 +982,71 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
                 }
             }
             __syncthreads();
-            if (tid < 8 * 16) {         // one DPP row per trial point (the eighth row idles along)
-                const int p = (tid >> 4) < kTailPoints ? (tid >> 4) : kTailPoints - 1;
-                const double sv = accumulate_by_row(0., terms + p * ts, n);
-                if ((tid & 15) == 0 && (tid >> 4) < kTailPoints) slopes[p] = sv;
+            // Tree sums first: wavefront p < 7 adds up the slope terms of trial point
+            // p, wavefront 8 + p their magnitudes.  They settle the search's questions
+            // unless a slope sits within rounding of the tolerance; only then are the
+            // terms added in row order (one DPP row per trial point, 6 microseconds).
+            {
+                const int w = tid >> 6, lane = tid & 63, p = w & 7;
+                if (p < kTailPoints) {
+                    const bool magnitude = w >= 8;
+                    const double* tv = terms + p * ts;
+                    double acc = 0.;
+                    for (int r = lane; r < n; r += kWave) {
+                        const double x = tv[r];
+                        acc += magnitude ? fabs(x) : x;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                    if (lane == 0) (magnitude ? mags : slopes)[p] = acc;
+                }
             }
             __syncthreads();
             // wavefront 0 walks down the tree along the slopes found and plans the
             // next round; everyone has read this round's plan before the first
             // barrier above
             if (tid < kWave) {
+                const Bisection before = bs;
+                bool settled = true;
                 int node = 1;
 #pragma unroll
                 for (int level = 0; level < kTailDepth; level++) {
-                    if (!bs.done) {
-                        const double sv = slopes[node - 1];
-                        const bool neg = bs.phase == 0 ? (sv / normal < 0.) : !(sv > 0);
-                        advance(bs, sv, normal);
-                        node = 2 * node + (neg ? 0 : 1);
+                    if (!bs.done && settled) {
+                        bool flat, neg;
+                        settled = slope_decided(slopes[node - 1], mags[node - 1], n, normal, &flat, &neg);
+                        if (settled) {
+                            advance_decided(bs, flat, neg);
+                            node = 2 * node + (neg ? 0 : 1);
+                        }
                     }
                 }
-                plan_round();
+                if (!settled) bs = before;
+                if (tid == 0) redo[0] = settled ? 0. : 1.;
+                if (settled) plan_round();
             }
             __syncthreads();
+            if (redo[0] != 0.) {
+                if (tid < 8 * 16) {     // one DPP row per trial point (the eighth row idles along)
+                    const int p = (tid >> 4) < kTailPoints ? (tid >> 4) : kTailPoints - 1;
+                    const double sv = accumulate_by_row(0., terms + p * ts, n);
+                    if ((tid & 15) == 0 && (tid >> 4) < kTailPoints) slopes[p] = sv;
+                }
+                __syncthreads();
+                if (tid < kWave) {
+                    int node = 1;
+#pragma unroll
+                    for (int level = 0; level < kTailDepth; level++) {
+                        if (!bs.done) {
+                            const double sv = slopes[node - 1];
+                            const bool neg = bs.phase == 0 ? (sv / normal < 0.) : !(sv > 0);
+                            advance(bs, sv, normal);
+                            node = 2 * node + (neg ? 0 : 1);
+                        }
+                    }
+                    plan_round();
+                }
+                __syncthreads();
+            }
         }
         if (tid == 0) {
             I.sc->alpha = bs.alpha;
