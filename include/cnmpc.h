@@ -61,7 +61,8 @@ enum nmpc_precision_t { NMPC_PRECISION_FLOAT = 0, NMPC_PRECISION_DOUBLE = 1 };
 
 /* c/cnmpc.h:52 -> ccs-c66x/cnmpc.c:872-948 */
 void nmpc_init(void);
-/* c/cnmpc.h:53 -> ccs-c66x/cnmpc.c:950-951 (empty there, empty here) */
+/* c/cnmpc.h:53 -> ccs-c66x/cnmpc.c:950-951 (empty there; empty here unless
+ * nmpc_set_rti(1) has been called) */
 void nmpc_preparation_step(void);
 /* c/cnmpc.h:54 -> ccs-c66x/cnmpc.c:953-956 */
 void nmpc_feedback_step(real_t measurement[NMPC_STATE_DIM]);
@@ -92,6 +93,9 @@ void nmpc_fixedwingdynamics_set_angular_velocity(real_t x, real_t y, real_t z);
 void nmpc_fixedwingdynamics_set_state(struct nmpc_state_t *in);
 void nmpc_fixedwingdynamics_get_state(struct nmpc_state_t *in);
 void nmpc_fixedwingdynamics_integrate(float dt, real_t control_vector[NMPC_CONTROL_DIM]);
+
+/* Not in the reference: nmpc_batch_set_rti for the hidden instance. */
+void nmpc_set_rti(int enabled);
 
 /* c/cnmpc.h:95-99 -> ccs-c66x/cnmpc.c:1088-1110 */
 uint32_t nmpc_config_get_state_dim(void);
@@ -178,8 +182,21 @@ int nmpc_batch_set_reference_from_waypoints_noalloc(nmpc_batch_t *b, const real_
                                                     uint32_t n_waypoints, real_t t0, real_t dt,
                                                     uint32_t first, uint32_t count);
 
-/* nmpc_preparation_step: no work (ccs-c66x/cnmpc.c:950-951). */
+/* nmpc_preparation_step: no work (ccs-c66x/cnmpc.c:950-951), unless the
+ * real-time-iteration mode below is on. */
 int nmpc_batch_preparation_step(nmpc_batch_t *b);
+
+/* Real-time-iteration mode (default off; no counterpart in the reference's
+ * code, whose preparation step is empty although its comments assign it this
+ * work: src/ocp.cpp:245-250, 315-322).  While on, the preparation step
+ * linearises every stage that carries a solution of the last feedback step
+ * about that solution, x = x_ref[k] (+) z_k[0:12], u = u_ref[k] + z_k[12:15],
+ * instead of about the reference trajectory, with C_k = d f / d (x, u) there
+ * and c_k = delta(x_ref[k+1], f(x, u)) - C_k z_k, and re-stages it.  Stages a
+ * reference point has linearised since the last feedback step (the new last
+ * stage after nmpc_batch_update_horizon) are left as they are.  Results then
+ * differ from the reference's; oracle/nmpc_port.c defines the arithmetic. */
+int nmpc_batch_set_rti(nmpc_batch_t *b, int enabled);
 
 /* Re-linearisation of every stage about the stored reference trajectory with
  * the current wind estimate and control bounds: what calling

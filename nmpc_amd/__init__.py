@@ -68,6 +68,12 @@ def prepare():
     _need().nmpc_preparation_step()
 
 
+def set_rti(enabled=True):
+    """Real-time-iteration mode (not in the reference module): prepare() then
+    re-linearises the horizon about the last solution; see nmpc_set_rti."""
+    _need().nmpc_set_rti(1 if enabled else 0)
+
+
 def solve(measurement):
     _need().nmpc_feedback_step((_REAL_T * _STATE_DIM)(*measurement))
 

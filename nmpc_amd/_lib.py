@@ -83,6 +83,8 @@ PROTOTYPES = {
     "nmpc_batch_set_reference_from_waypoints_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32,
                                                                   REAL, REAL, C.c_uint32, C.c_uint32]),
     "nmpc_batch_preparation_step": (C.c_int, [C.c_void_p]),
+    "nmpc_batch_set_rti": (C.c_int, [C.c_void_p, C.c_int]),
+    "nmpc_set_rti": (None, [C.c_int]),
     "nmpc_batch_relinearise": (C.c_int, [C.c_void_p]),
     "nmpc_batch_feedback_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nmpc_batch_get_controls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -137,6 +137,11 @@ class Batch:
     def prepare(self):
         self._ck(self.lib.nmpc_batch_preparation_step(self.h))
 
+    def set_rti(self, enabled=True):
+        """Real-time-iteration mode: prepare() re-linearises the stages about the
+        last solution (see nmpc_batch_set_rti).  Off by default."""
+        self._ck(self.lib.nmpc_batch_set_rti(self.h, 1 if enabled else 0))
+
     def relinearise(self):
         """Every stage linearised again about the stored references at the current
         wind estimate (see nmpc_batch_relinearise)."""

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -94,6 +95,11 @@ struct nmpc_batch {
     double wq[12], wr[3], wt[12], lb[3], ub[3];
     double init_lb[3], init_ub[3];      // control bounds as nmpc_batch_init saw them
     bool initialised = false;
+    // Real-time-iteration preparation (nmpc_batch_set_rti): fresh[k] != 0 while
+    // horizon position k has been linearised about the reference since the last
+    // feedback step, i.e. carries no solution to linearise about.
+    bool rti = false;
+    std::vector<char> fresh;
     Staging in_refs, in_meas, in_wind, out_u, out_status, out_iters, scratch;
     // nmpc_batch_init leaves the Jacobians C and residuals c logically zero; the
     // clear itself is postponed until something is about to read or partly
@@ -319,6 +325,7 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
     memset(b->wq, 0, sizeof b->wq); memset(b->wr, 0, sizeof b->wr);
     memset(b->wt, 0, sizeof b->wt); memset(b->lb, 0, sizeof b->lb);
     memset(b->ub, 0, sizeof b->ub);
+    b->fresh.assign(N, 1);
     *out = b;
     return 0;
 }
@@ -354,6 +361,7 @@ int nmpc_batch_reset(nmpc_batch_t* b) {
     b->stage_init_pending = false;      // what it would write is zero again
     b->v.head = b->v.xhead = b->v.lhead = 0;
     b->initialised = false;
+    std::fill(b->fresh.begin(), b->fresh.end(), 1);
     return 0;
 }
 
@@ -399,6 +407,7 @@ int nmpc_batch_init(nmpc_batch_t* b) {
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_init_stages(v, 1, b->stream); }));
     b->stage_init_pending = true;
     b->initialised = true;
+    std::fill(b->fresh.begin(), b->fresh.end(), 1);    // no solution to linearise about yet
     return 0;
 }
 
@@ -426,10 +435,12 @@ static int store_and_linearise(nmpc_batch* b, const double* dev, uint32_t first,
         b->jacobians_zero_pending = b->stage_init_pending = false;  // every stage is rewritten below
     else
         TRY(materialise_jacobians(b));
-    if (lin_count > 0)
+    if (lin_count > 0) {
         TRY(timed(b, NMPC_K_LINEARISE, [&] {
             launch_linearise(b->v, lin_first, lin_count, b->stream);
         }));
+        std::fill(b->fresh.begin() + lin_first, b->fresh.begin() + lin_first + lin_count, 1);
+    }
     return 0;
 }
 
@@ -531,8 +542,31 @@ int nmpc_batch_set_reference_from_waypoints_noalloc(nmpc_batch_t* b, const real_
     return store_and_linearise(b, points_dev, first, count);
 }
 
+int nmpc_batch_set_rti(nmpc_batch_t* b, int enabled) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    b->rti = enabled != 0;
+    return 0;
+}
+
 int nmpc_batch_preparation_step(nmpc_batch_t* b) {
     if (!b) return fail(NMPC_E_ARG, "null batch");
+    if (!b->rti || !b->initialised) return 0;      // the reference's preparation step is empty
+    TRY(use_device(b));
+    sync_config(b);
+    TRY(materialise_jacobians(b));
+    if (b->stage_zero_pending) TRY(materialise_stage_vectors(b));
+    // runs of horizon positions that carry a solution of the last feedback step
+    const int N = b->v.N;
+    for (int k = 0; k < N;) {
+        if (b->fresh[k]) { ++k; continue; }
+        int e = k;
+        while (e < N && !b->fresh[e]) ++e;
+        TRY(timed(b, NMPC_K_LINEARISE, [&] {
+            launch_linearise(b->v, k, e - k, b->stream, true);
+        }));
+        std::fill(b->fresh.begin() + k, b->fresh.begin() + e, 1);
+        k = e;
+    }
     return 0;
 }
 
@@ -543,6 +577,7 @@ int nmpc_batch_relinearise(nmpc_batch_t* b) {
     sync_config(b);
     b->jacobians_zero_pending = b->stage_init_pending = false;      // every stage is rewritten
     TRY(timed(b, NMPC_K_LINEARISE, [&] { launch_linearise(b->v, 0, b->v.N, b->stream); }));
+    std::fill(b->fresh.begin(), b->fresh.end(), 1);
     return 0;
 }
 
@@ -572,6 +607,7 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
             TRY(timed(b, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, b->stream); }));
     }
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_qp_finish(v, b->stream); }));
+    std::fill(b->fresh.begin(), b->fresh.end(), 0);     // every stage now carries a solution
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -621,6 +657,8 @@ int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
         launch_store_refs(v, (const double*)dev, v.N, 1, b->stream);
     }));
     TRY(timed(b, NMPC_K_LINEARISE, [&] { launch_linearise(v, v.N - 1, 1, b->stream); }));
+    b->fresh.erase(b->fresh.begin());       // the stage records moved up by one position
+    b->fresh.push_back(1);
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -946,7 +984,11 @@ void nmpc_init(void) {
     MUST(nmpc_batch_set_wind_velocity(b, g_single.wind));
 }
 
-void nmpc_preparation_step(void) {}
+void nmpc_preparation_step(void) {
+    if (g_single.batch) MUST(nmpc_batch_preparation_step(g_single.batch));
+}
+
+void nmpc_set_rti(int enabled) { MUST(nmpc_batch_set_rti(single(), enabled)); }
 
 void nmpc_feedback_step(real_t measurement[NMPC_STATE_DIM]) {
     nmpc_batch* b = single();

@@ -167,9 +167,17 @@ NMPC_DEV void bcast_from_last(double (&out)[NS], const double (&in)[NS],
     ((out[I] = row_bcast<15>(in[I])), ...);
 }
 
+// zdev: null, or the stage variable z (15 entries) the expansion point is moved
+// by: x (+) z[0:12], u + z[12:15]; this lane's entry of it comes back in *zj.
+template <int... I>
+NMPC_DEV void gather_row15(double (&out)[NZ], double mine, std::integer_sequence<int, I...>) {
+    ((out[I] = row_bcast<I>(mine)), ...);
+}
+
 NMPC_DEV void linearise_lane(const double* xr, const double* xq, const double* ur,
                              const double* wr, const double* lower, const double* upper,
-                             int j, double* out12) {
+                             int j, double* out12, const double* zdev = nullptr,
+                             double* zj = nullptr) {
     using Seq13 = std::make_integer_sequence<int, NS>;
     const int li = j < NS ? j : 0;
     const double mine = xr[li], mine_next = xq[li];
@@ -177,6 +185,17 @@ NMPC_DEV void linearise_lane(const double* xr, const double* xq, const double* u
     gather_row(x, mine, Seq13{});
 #pragma unroll
     for (int i = 0; i < NU; i++) { u[i] = ur[i]; wind[i] = wr[i]; }
+    if (zdev) {
+        const double zmine = zdev[j < NZ ? j : 0];
+        double z[NZ], x0[NS];
+        gather_row15(z, zmine, std::make_integer_sequence<int, NZ>{});
+#pragma unroll
+        for (int i = 0; i < NS; i++) x0[i] = x[i];
+        state_plus_delta(x, x0, z);
+#pragma unroll
+        for (int i = 0; i < NU; i++) u[i] = u[i] + z[NX + i];
+        *zj = zmine;
+    }
     const double hinv = perturb_point(x, u, j, lower, upper);
     rk4_step(moved, x, u, wind, kStepLength);
     bcast_from_last(base, moved, Seq13{});              // nominal end state
@@ -201,6 +220,18 @@ NMPC_DEV double dot_with_row(const double (&col)[NX], double mine, std::integer_
 // before the integration, one value per lane (a wavefront that asked for them
 // afterwards would sit out the memory latency with nothing left to do), and
 // the multiplier block is shared out by row broadcasts at the end.
+// ABOUT_SOLUTION: the expansion point of every stage is moved by the stage's
+// current solution z and the residual is taken back by C z, so that the stage
+// stays a deviation from the reference: c = delta(x_ref[k+1], f(x, u)) - C z
+// (the real-time-iteration preparation step; the reference has no code for it).
+template <int... J>
+NMPC_DEV double sum_over_columns(double mine, std::integer_sequence<int, J...>) {
+    double acc = 0.;
+    ((acc += row_bcast<J>(mine)), ...);
+    return acc;
+}
+
+template <bool ABOUT_SOLUTION>
 __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchView v, int first, int count) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int j = (int)(gid & 15);
@@ -233,8 +264,19 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
     double col[NX];
     {
         const double* xref = v.xref + (size_t)b * (v.N + 1) * NS;
+        double zj = 0.;
+        const double* zdev = ABOUT_SOLUTION ? v.z + ((size_t)b * (v.N + 1) + s) * NZ : nullptr;
         linearise_lane(xref + (size_t)xref_slot(v, k) * NS, xref + (size_t)xref_slot(v, k + 1) * NS,
-                       ur, v.wind + (size_t)b * 3, v.lb, v.ub, j, col);
+                       ur, v.wind + (size_t)b * 3, v.lb, v.ub, j, col, zdev, &zj);
+        if (ABOUT_SOLUTION) {
+            // row r of C z: the columns' products added in column order; lane 15 keeps them
+#pragma unroll
+            for (int r = 0; r < NX; r++) {
+                const double prod = (j < NZ) ? col[r] * zj : 0.;
+                const double cz = sum_over_columns(prod, std::make_integer_sequence<int, NZ>{});
+                if (j == 15) col[r] = col[r] - cz;
+            }
+        }
     }
     // C' lambda_{k+1} (lanes j < 15) and c . lambda_{k+1} (lane 15): the same sum
     const double dot = dot_with_row(col, lam_next, Seq12{});
@@ -366,9 +408,12 @@ void launch_init_stages(const BatchView& v, int part, hipStream_t s) {
     const long n = (long)v.B * (v.N + 1) * NZ;
     hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, part);
 }
-void launch_linearise(const BatchView& v, int first, int count, hipStream_t s) {
+void launch_linearise(const BatchView& v, int first, int count, hipStream_t s, bool about_solution) {
     const long n = (long)v.B * count * 16;
-    hipLaunchKernelGGL(k_linearise, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, first, count);
+    if (about_solution)
+        hipLaunchKernelGGL(k_linearise<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, first, count);
+    else
+        hipLaunchKernelGGL(k_linearise<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, first, count);
 }
 void launch_linearise_free(long n, const double* x, const double* u, const double* xn,
                            const double* w, const Bounds& bnd, double* jac, double* res,

@@ -12,7 +12,9 @@ void launch_store_refs(const BatchView& v, const double* refs, int first, int co
 void launch_refs_from_waypoints(int B, const double* wp, int W, double t0, double dt, int first,
                                 int count, double* out, hipStream_t s);
 void launch_init_stages(const BatchView& v, int part, hipStream_t s);
-void launch_linearise(const BatchView& v, int first, int count, hipStream_t s);
+// about_solution: expansion point moved by each stage's current z (see k_linearise)
+void launch_linearise(const BatchView& v, int first, int count, hipStream_t s,
+                      bool about_solution = false);
 void launch_linearise_free(long n, const double* x, const double* u, const double* xnext,
                            const double* wind, const Bounds& bnd, double* jac, double* res,
                            hipStream_t s);

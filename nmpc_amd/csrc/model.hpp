@@ -254,6 +254,26 @@ NMPC_DEV void state_to_delta(double* dl, const double* s1, const double* s2) {
     dl[6] = e[0] * d; dl[7] = e[1] * d; dl[8] = e[2] * d;
 }
 
+// x (+) d: the state a 12-vector deviation d leads to from x.  Position,
+// velocity and body rates add; the attitude deviation is applied as the MRP
+// (a = 1, f = 4) quaternion multiplied from the left, the composition the
+// finite differences use (ccs-c66x/cnmpc.c:617-634), with the scalar part in
+// its intended form (src/ocp.cpp:122-126).  x and out may not alias.
+NMPC_DEV void state_plus_delta(double* out, const double* x, const double* d) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        out[i] = x[i] + d[i];
+        out[3 + i] = x[3 + i] + d[3 + i];
+        out[10 + i] = x[10 + i] + d[9 + i];
+    }
+    const double pp = d[6] * d[6] + d[7] * d[7] + d[8] * d[8];
+    double dq[4];
+    dq[3] = (16.0 - pp) / (16.0 + pp);
+    const double sc = 0.25 * (1.0 + dq[3]);
+    dq[0] = sc * d[6]; dq[1] = sc * d[7]; dq[2] = sc * d[8];
+    quat_mul(&out[6], dq, &x[6]);
+}
+
 // Perturbed copy of (x, u) for finite-difference column j of the stage
 // Jacobian (ccs-c66x/cnmpc.c:600-648).  j == 15 leaves the point unperturbed.
 // Returns 1/h for the column.

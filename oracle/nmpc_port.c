@@ -69,6 +69,7 @@ typedef struct {
     double tmp[NZ];             /* trial vector (zVecTmp) */
     int nV;
     int changed;                /* actSetHasChanged */
+    int fresh;                  /* linearised about the reference since the last solve */
 } stage_t;
 
 struct port_s {
@@ -390,6 +391,7 @@ void port_init(port_t *p) {
     for (int k = 0; k <= N; k++) {
         p->slot[k] = k;
         p->rec[k].nV = (k < N) ? NZ : NX;
+        p->rec[k].fresh = 1;        /* no solution to linearise about yet */
     }
     mark_data_changed(p);
 
@@ -428,6 +430,7 @@ void port_set_reference_point(port_t *p, const double *ref, unsigned i) {
         }
         port_linearise(&p->xref[k * NS], ur, ref, p->wind, p->lb, p->ub, s->C, s->c);
         restage(p, k);
+        s->fresh = 1;
     }
 }
 
@@ -828,12 +831,63 @@ void port_feedback_step(port_t *p, const double *meas) {
         s0->zUpp[NX + i] = p->ub[i] - p->uref[i];
     }
     mark_data_changed(p);
+    for (int k = 0; k < p->N; k++) stage_at(p, k)->fresh = 0;
     p->lastStatus = dual_newton_solve(p);
     if (p->lastStatus == ST_OPTIMAL) {
         for (int i = 0; i < NU; i++) p->u[i] = p->uref[i] + s0->z[NX + i];
         p->lastResult = 1;
     } else {
         p->lastResult = 0;
+    }
+}
+
+/*
+ * Real-time-iteration preparation step.  The reference leaves its preparation
+ * step empty (cnmpc.c:950-951, src/ocp.cpp:245-250) although its comments give
+ * it the re-linearisation of the horizon (src/ocp.cpp:315-322); this is that
+ * work, defined here because the reference holds no code for it: every stage
+ * that carries a solution of the last feedback step (all but those a reference
+ * point has re-linearised since) is linearised about that solution instead of
+ * about the reference trajectory,
+ *     x = x_ref[k] (+) z_k[0:12],  u = u_ref[k] + z_k[12:15],
+ * where (+) adds position, velocity and body rates and applies the attitude
+ * deviation as the MRP (a = 1, f = 4) quaternion multiplied from the left, the
+ * composition the finite differences use (cnmpc.c:617-634) with the scalar part
+ * in its intended form (16 - p.p) / (16 + p.p) (src/ocp.cpp:122-126).  The stage
+ * keeps its meaning as a deviation from the reference:
+ *     C_k = d f / d (x, u) at (x, u),   c_k = delta(x_ref[k+1], f(x, u)) - C_k z_k,
+ * and is re-staged like any stage whose data changed (setup_qp.c:415-474).
+ */
+void port_state_plus_delta(double *out, const double *x, const double *d) {
+    for (int i = 0; i < 3; i++) {
+        out[i] = x[i] + d[i];
+        out[3 + i] = x[3 + i] + d[3 + i];
+        out[10 + i] = x[10 + i] + d[9 + i];
+    }
+    double pp = d[6] * d[6] + d[7] * d[7] + d[8] * d[8];
+    double dq[4];
+    dq[3] = (16.0 - pp) / (16.0 + pp);
+    double sc = 0.25 * (1.0 + dq[3]);
+    dq[0] = sc * d[6]; dq[1] = sc * d[7]; dq[2] = sc * d[8];
+    quat_mul(&out[6], dq, &x[6]);
+}
+
+void port_preparation_step_rti(port_t *p) {
+    int N = p->N;
+    for (int k = 0; k < N; k++) {
+        stage_t *s = stage_at(p, k);
+        if (s->fresh) continue;
+        double x[NS], u[NU];
+        port_state_plus_delta(x, &p->xref[k * NS], s->z);
+        for (int i = 0; i < NU; i++) u[i] = p->uref[k * NU + i] + s->z[NX + i];
+        port_linearise(x, u, &p->xref[(k + 1) * NS], p->wind, p->lb, p->ub, s->C, s->c);
+        for (int r = 0; r < NX; r++) {
+            double acc = 0.;
+            for (int j = 0; j < NZ; j++) acc += s->C[r * NZ + j] * s->z[j];
+            s->c[r] = s->c[r] - acc;
+        }
+        restage(p, k);
+        s->fresh = 1;
     }
 }
 

@@ -38,6 +38,12 @@ void port_feedback_step(port_t *p, const double *meas13);
 int port_get_controls(port_t *p, double *u3);    /* 0 OK, 1 INFEASIBLE */
 void port_update_horizon(port_t *p, const double *ref16);
 
+/* Real-time-iteration preparation step (no code for it in the reference, whose
+ * preparation step is empty): re-linearises every stage that carries a solution
+ * of the last feedback step about that solution.  See nmpc_port.c. */
+void port_preparation_step_rti(port_t *p);
+void port_state_plus_delta(double *out13, const double *x13, const double *d12);
+
 /* introspection, same record layout as oracle/ref_wrap.c */
 int port_horizon(const port_t *p);
 int port_num_iter(const port_t *p);

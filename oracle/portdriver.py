@@ -69,6 +69,8 @@ def lib():
         L.port_batch_cold_solve.restype = C.c_double
         L.port_batch_cold_solve.argtypes = (
             [C.c_int] * 3 + [dp] * 8 + [dp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        L.port_preparation_step_rti.argtypes = [vp]
+        L.port_preparation_step_rti.restype = None
         L.port_batch_linearise.restype = C.c_double
         L.port_batch_linearise.argtypes = [C.c_long, C.c_int] + [dp] * 8
         _lib = L
@@ -117,6 +119,9 @@ class Port:
         u = np.zeros(3)
         st = self.lib.port_get_controls(self.h, _dp(u))
         return u, st
+
+    def prepare_rti(self):
+        self.lib.port_preparation_step_rti(self.h)
 
     def update_horizon(self, point):
         self.lib.port_update_horizon(self.h, _dp(_f(point, 16)))

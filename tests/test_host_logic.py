@@ -52,3 +52,26 @@ def test_partition_is_contiguous_and_complete():
                 assert a[1] == b[0]
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_state_plus_delta_inverts_state_to_delta(port_built):
+    """x (+) d of the real-time-iteration preparation step is the inverse of the
+    reference's state difference (ccs-c66x/cnmpc.c:541-579) up to rounding."""
+    import ctypes as C
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    lib = P.lib()
+    dp = C.POINTER(C.c_double)
+    lib.port_state_plus_delta.argtypes = [dp, dp, dp]
+    rng = np.random.default_rng(4)
+    x, _, _ = S.random_states(200, rng)
+    for i in range(200):
+        d = rng.normal(0, 0.3, 12)
+        out = np.zeros(13)
+        lib.port_state_plus_delta(out.ctypes.data_as(dp), x[i].ctypes.data_as(dp), d.ctypes.data_as(dp))
+        back = P.state_to_delta(x[i], out)
+        np.testing.assert_allclose(back, d, rtol=0, atol=1e-12)
+    z = np.zeros(12)
+    out = np.zeros(13)
+    lib.port_state_plus_delta(out.ctypes.data_as(dp), x[0].ctypes.data_as(dp), z.ctypes.data_as(dp))
+    assert np.array_equal(out, x[0])
