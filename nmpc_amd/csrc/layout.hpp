@@ -70,7 +70,7 @@ struct BatchView {
     double* qStep;
     double* zUnc;
     double* dz;
-    double* tmp;        // trial primal vector of the line search
+    double* tmp;        // trial primal vector of the line search; between solves' kernels scratch of k_newton_solve
     double* y;          // [B][N+1][30]   (lb - z, z - ub) pairs
     double* p;          // [B][N+1]
     double* pStep;      // [B][N+1]

@@ -357,12 +357,16 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
             }
             if (factorThis && col) {
                 // whole rows: the entries right of the diagonal are zero in the
-                // reference's factor too (it never writes them)
+                // reference's factor too (it never writes them).  A failed pivot in
+                // column failCol ends the reference's factorisation before it writes
+                // row failCol (dual_qp.c:855-866): the rows below it stay as they were.
 #pragma unroll
-                for (int l = 0; l < NX; l++) HS(I.chol, k, 0, l, t) = (l >= t) ? L[l] : 0.;
+                for (int l = 0; l < NX; l++)
+                    if (l > failCol) HS(I.chol, k, 0, l, t) = (l >= t) ? L[l] : 0.;
                 if (k > 0) {
 #pragma unroll
-                    for (int l = 0; l < NX; l++) HS(I.chol, k, -1, l, t) = Ls[l];
+                    for (int l = 0; l < NX; l++)
+                        if (l > failCol) HS(I.chol, k, -1, l, t) = Ls[l];
                 }
             }
             if (factorThis && failCol >= 0) status = ST_DIV_ZERO;
@@ -376,7 +380,8 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
             backsolve_rows<false>(xk, mine, L, pn, g, pv, t, Seq12{});
         else
             backsolve_rows<true>(xk, mine, L, pn, g, pv, t, Seq12{});
-        if (active && status == ST_OK && col) I.dl[k * NX + t] = mine;
+        // into scratch: the step itself is only written once the factor is known to be good
+        if (active && status == ST_OK && col) I.tmp[k * NX + t] = mine;
 #pragma unroll
         for (int j = 0; j < NX; j++) { pn[j] = Ls[j] * xk[j]; Ln[j] = Ls[j]; }
     }
@@ -401,7 +406,7 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
     if (live) {
 #pragma unroll
         for (int j = 0; j < NX; j++) { nLd[j] = HS(I.chol, 0, 0, tc, j); nLr[j] = HS(I.chol, 0, -1, tc, j); }
-        nsum = I.dl[tc];
+        nsum = I.tmp[tc];
         nd = HS(I.chol, 0, 0, tc, tc);
     }
     for (int k = 0; k < N; ++k) {
@@ -416,7 +421,7 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
                 nLd[j] = HS(I.chol, k + 1, 0, tc, j);
                 nLr[j] = HS(I.chol, k + 1, -1, tc, j);
             }
-            nsum = I.dl[(k + 1) * NX + tc];
+            nsum = I.tmp[(k + 1) * NX + tc];
             nd = HS(I.chol, k + 1, 0, tc, tc);
         }
         if (k > 0) {

@@ -158,6 +158,16 @@ def gen_sequences():
     run_sequence("seq_exact", N, refs, refs[:5, :13], [(0, [1.0, -2.0, 0.5])], 5)
 
 
+def gen_indefinite():
+    """Negative state weights: the Newton Hessian is not positive definite even
+    after the solver's one regularisation, so the factorisation fails twice and
+    the solve ends with a division-by-zero status (dual_qp.c:643-689)."""
+    N = 100
+    d = S.make_batch(1, N, extra_steps=3, seed=5)
+    run_sequence("seq_indefinite", N, d["refs"][0], d["meas"][0], [(0, d["wind"][0])], 3,
+                 weights=dict(state_weights=[1, 1, 1, -1, -1, -1, 1, 1, 1, 1, 1, 1]), dump=True)
+
+
 def gen_long_horizon():
     from refdriver import have_ref
     if not have_ref(500):
@@ -171,7 +181,8 @@ def gen_long_horizon():
 
 
 if __name__ == "__main__":
-    gen_model()
-    gen_linearise()
-    gen_sequences()
-    gen_long_horizon()
+    import sys
+    parts = dict(model=gen_model, linearise=gen_linearise, sequences=gen_sequences,
+                 indefinite=gen_indefinite, long_horizon=gen_long_horizon)
+    for name in (sys.argv[1:] or list(parts)):      # no argument: everything
+        parts[name]()

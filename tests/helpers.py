@@ -8,7 +8,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SEQUENCES = ["seq_straight", "seq_turn0", "seq_turn1", "seq_turn2", "seq_turn3",
              "seq_turn4", "seq_turn5", "seq_bound", "seq_identity", "seq_regularised",
-             "seq_linesearch", "seq_exact", "seq_n500_0", "seq_n500_1"]
+             "seq_linesearch", "seq_exact", "seq_indefinite", "seq_n500_0", "seq_n500_1"]
 
 
 def golden(name):
