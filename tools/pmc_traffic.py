@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/prof_run.py
-into profiles/traffic.json: mean HBM bytes per launch of every nmpc kernel.
+"""Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a profiling
+workload into profiles/r02_traffic_<tag>.json: mean HBM bytes per launch of
+every nmpc kernel.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write ...csv> B N
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write ...csv> <tag> <workload text>
 
 FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte
 read requests as 64 bytes, so the read side is doubled.  Cross-check of the
@@ -16,8 +17,10 @@ import re
 import sys
 from collections import defaultdict
 
-SHORT = {"k_linearise": "linearise", "k_qp_begin": "qp_begin", "k_newton_solve": "newton_solve",
-         "k_newton_step": "newton_step", "k_init_stages": "init_stages"}
+SHORT = {"k_linearise": "linearise", "k_linearise_free": "linearise_free", "k_qp_begin": "qp_begin",
+         "k_newton_solve": "newton_solve", "k_newton_step": "newton_step",
+         "k_init_stages": "init_stages", "k_line_search_tail": "line_search_tail",
+         "k_line_search_commit": "line_search_commit", "k_line_search_hessian": "line_search_hessian"}
 
 
 def collect(path, counter):
@@ -26,19 +29,19 @@ def collect(path, counter):
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            m = re.search(r"nmpc::(\w+)\(", row["Kernel_Name"])
+            m = re.search(r"nmpc::(\w+)", row["Kernel_Name"])
             name = m.group(1) if m else row["Kernel_Name"].split("(")[0]
             per[name].append(float(row["Counter_Value"]))
     return per
 
 
 def main():
-    fetch_csv, write_csv, B, N = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    fetch_csv, write_csv, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
     fetch = collect(fetch_csv, "FETCH_SIZE")
     write = collect(write_csv, "WRITE_SIZE")
-    out = {"instances": B, "horizon": N,
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over "
-                     "tools/prof_run.py; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+    out = {"workload": workload,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; "
+                     "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over the launches",
            "bytes_per_launch": {}, "read_bytes_per_launch": {}, "write_bytes_per_launch": {},
            "launches": {}}
     for name in sorted(set(fetch) | set(write)):
@@ -52,10 +55,10 @@ def main():
         out["write_bytes_per_launch"][k] = round(w)
         out["launches"][k] = len(fetch.get(name, []))
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       "profiles", "traffic.json")
+                       "gpurun_out", "r02_traffic_%s.json" % tag)
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps(out, indent=1))
+    print(tag, json.dumps(out["bytes_per_launch"]))
 
 
 if __name__ == "__main__":
