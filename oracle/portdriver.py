@@ -10,32 +10,40 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 STAGE_REC = 332
 LIB_PATH = os.path.join(HERE, "libnmpc_port.so")
+LIB_PATHS = {"double": LIB_PATH, "float": os.path.join(HERE, "libnmpc_port_f32.so")}
+DTYPES = {"double": np.float64, "float": np.float32}
+CTYPES = {"double": C.c_double, "float": C.c_float}
 
-_lib = None
+_libs = {}
 
 
 def _dp(a):
-    return a.ctypes.data_as(C.POINTER(C.c_double))
+    ct = C.c_double if a.dtype == np.float64 else C.c_float
+    return a.ctypes.data_as(C.POINTER(ct))
 
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))
 
 
-def _f(v, n=None):
-    a = np.ascontiguousarray(v, dtype=np.float64)
+def _f(v, n=None, precision="double"):
+    a = np.ascontiguousarray(v, dtype=DTYPES[precision])
     if n is not None:
         assert a.size == n, (a.shape, n)
     return a
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FileNotFoundError(LIB_PATH + " (run `make -C oracle port`)")
-        L = C.CDLL(LIB_PATH)
-        dp, vp = C.POINTER(C.c_double), C.c_void_p
+def lib(precision="double"):
+    """The port built for `precision`: "double", or "float" (the reference's
+    shipped single-precision configuration)."""
+    if precision not in _libs:
+        path = LIB_PATHS[precision]
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (run `make -C oracle port`)")
+        L = C.CDLL(path)
+        real = CTYPES[precision]
+        assert L.port_real_bytes() == C.sizeof(real)
+        dp, vp = C.POINTER(real), C.c_void_p
         L.port_create.restype = vp
         L.port_create.argtypes = [C.c_int]
         L.port_destroy.argtypes = [vp]
@@ -46,7 +54,7 @@ def lib():
             getattr(L, n).argtypes = [vp, dp]
             getattr(L, n).restype = None
         L.port_get_controls.argtypes = [vp, dp]
-        L.port_set_wind_velocity.argtypes = [vp] + [C.c_double] * 3
+        L.port_set_wind_velocity.argtypes = [vp] + [real] * 3
         L.port_set_wind_velocity.restype = None
         L.port_init.argtypes = [vp]
         L.port_init.restype = None
@@ -57,13 +65,13 @@ def lib():
                   "port_hessian_regularized"):
             getattr(L, n).argtypes = [vp]
         L.port_alpha.argtypes = [vp]
-        L.port_alpha.restype = C.c_double
+        L.port_alpha.restype = real
         L.port_get_stage.argtypes = [vp, C.c_uint, dp]
         L.port_global_size.argtypes = [vp]
         L.port_global_size.restype = C.c_uint
         L.port_x8_dynamics.argtypes = [dp] * 4
         L.port_state_model.argtypes = [dp] * 4
-        L.port_rk4.argtypes = [dp] * 4 + [C.c_double]
+        L.port_rk4.argtypes = [dp] * 4 + [real]
         L.port_state_to_delta.argtypes = [dp] * 3
         L.port_linearise.argtypes = [dp] * 8
         L.port_batch_cold_solve.restype = C.c_double
@@ -73,17 +81,19 @@ def lib():
         L.port_preparation_step_rti.restype = None
         L.port_batch_linearise.restype = C.c_double
         L.port_batch_linearise.argtypes = [C.c_long, C.c_int] + [dp] * 8
-        _lib = L
-    return _lib
+        _libs[precision] = L
+    return _libs[precision]
 
 
-def have_port():
-    return os.path.exists(LIB_PATH)
+def have_port(precision="double"):
+    return os.path.exists(LIB_PATHS[precision])
 
 
 class Port:
-    def __init__(self, n=100):
-        self.lib = lib()
+    def __init__(self, n=100, precision="double"):
+        self.lib = lib(precision)
+        self.precision = precision
+        self.dtype = DTYPES[precision]
         self.N = n
         self.h = self.lib.port_create(n)
         from refdriver import global_fields
@@ -97,26 +107,26 @@ class Port:
             pass
 
     def setup(self, state_w, control_w, terminal_w, upper, lower):
-        self.lib.port_set_state_weights(self.h, _dp(_f(state_w, 12)))
-        self.lib.port_set_control_weights(self.h, _dp(_f(control_w, 3)))
-        self.lib.port_set_terminal_weights(self.h, _dp(_f(terminal_w, 12)))
-        self.lib.port_set_lower_control_bound(self.h, _dp(_f(lower, 3)))
-        self.lib.port_set_upper_control_bound(self.h, _dp(_f(upper, 3)))
+        self.lib.port_set_state_weights(self.h, _dp(_f(state_w, 12, precision=self.precision)))
+        self.lib.port_set_control_weights(self.h, _dp(_f(control_w, 3, precision=self.precision)))
+        self.lib.port_set_terminal_weights(self.h, _dp(_f(terminal_w, 12, precision=self.precision)))
+        self.lib.port_set_lower_control_bound(self.h, _dp(_f(lower, 3, precision=self.precision)))
+        self.lib.port_set_upper_control_bound(self.h, _dp(_f(upper, 3, precision=self.precision)))
 
     def init(self):
         self.lib.port_init(self.h)
 
     def set_reference(self, point, i):
-        self.lib.port_set_reference_point(self.h, _dp(_f(point, 16)), i)
+        self.lib.port_set_reference_point(self.h, _dp(_f(point, 16, precision=self.precision)), i)
 
     def set_wind(self, w):
         self.lib.port_set_wind_velocity(self.h, float(w[0]), float(w[1]), float(w[2]))
 
     def feedback(self, meas):
-        self.lib.port_feedback_step(self.h, _dp(_f(meas, 13)))
+        self.lib.port_feedback_step(self.h, _dp(_f(meas, 13, precision=self.precision)))
 
     def controls(self):
-        u = np.zeros(3)
+        u = np.zeros(3, dtype=self.dtype)
         st = self.lib.port_get_controls(self.h, _dp(u))
         return u, st
 
@@ -124,19 +134,19 @@ class Port:
         self.lib.port_preparation_step_rti(self.h)
 
     def update_horizon(self, point):
-        self.lib.port_update_horizon(self.h, _dp(_f(point, 16)))
+        self.lib.port_update_horizon(self.h, _dp(_f(point, 16, precision=self.precision)))
 
     def num_iter(self):
         return self.lib.port_num_iter(self.h)
 
     def stages(self):
-        out = np.zeros((self.N + 1, STAGE_REC))
+        out = np.zeros((self.N + 1, STAGE_REC), dtype=self.dtype)
         for k in range(self.N + 1):
             self.lib.port_get_stage(self.h, k, _dp(out[k]))
         return out
 
     def globals_(self):
-        out = np.zeros(self.gsize)
+        out = np.zeros(self.gsize, dtype=self.dtype)
         self.lib.port_get_global(self.h, _dp(out))
         return out
 
@@ -146,58 +156,59 @@ class Port:
 
 
 # -- model functions ------------------------------------------------------
-def x8_dynamics(x, u, wind):
-    out = np.zeros(6)
-    lib().port_x8_dynamics(_dp(out), _dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(wind, 3)))
+def x8_dynamics(x, u, wind, precision="double"):
+    out = np.zeros(6, dtype=DTYPES[precision])
+    lib(precision).port_x8_dynamics(_dp(out), _dp(_f(x, 13, precision=precision)), _dp(_f(u, 3, precision=precision)), _dp(_f(wind, 3, precision=precision)))
     return out
 
 
-def state_model(x, u, wind):
-    out = np.zeros(13)
-    lib().port_state_model(_dp(out), _dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(wind, 3)))
+def state_model(x, u, wind, precision="double"):
+    out = np.zeros(13, dtype=DTYPES[precision])
+    lib(precision).port_state_model(_dp(out), _dp(_f(x, 13, precision=precision)), _dp(_f(u, 3, precision=precision)), _dp(_f(wind, 3, precision=precision)))
     return out
 
 
-def rk4(x, u, wind, delta=1.0 / 50.0):
-    out = np.zeros(13)
-    lib().port_rk4(_dp(out), _dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(wind, 3)), delta)
+def rk4(x, u, wind, delta=1.0 / 50.0, precision="double"):
+    out = np.zeros(13, dtype=DTYPES[precision])
+    lib(precision).port_rk4(_dp(out), _dp(_f(x, 13, precision=precision)), _dp(_f(u, 3, precision=precision)), _dp(_f(wind, 3, precision=precision)), delta)
     return out
 
 
-def state_to_delta(s1, s2):
-    out = np.zeros(12)
-    lib().port_state_to_delta(_dp(out), _dp(_f(s1, 13)), _dp(_f(s2, 13)))
+def state_to_delta(s1, s2, precision="double"):
+    out = np.zeros(12, dtype=DTYPES[precision])
+    lib(precision).port_state_to_delta(_dp(out), _dp(_f(s1, 13, precision=precision)), _dp(_f(s2, 13, precision=precision)))
     return out
 
 
-def linearise(x, u, xnext, wind, lower, upper):
-    jac, res = np.zeros(180), np.zeros(12)
-    lib().port_linearise(_dp(_f(x, 13)), _dp(_f(u, 3)), _dp(_f(xnext, 13)),
-                         _dp(_f(wind, 3)), _dp(_f(lower, 3)), _dp(_f(upper, 3)),
+def linearise(x, u, xnext, wind, lower, upper, precision="double"):
+    jac, res = np.zeros(180, dtype=DTYPES[precision]), np.zeros(12, dtype=DTYPES[precision])
+    lib(precision).port_linearise(_dp(_f(x, 13, precision=precision)), _dp(_f(u, 3, precision=precision)), _dp(_f(xnext, 13, precision=precision)),
+                         _dp(_f(wind, 3, precision=precision)), _dp(_f(lower, 3, precision=precision)), _dp(_f(upper, 3, precision=precision)),
                          _dp(jac), _dp(res))
     return jac, res
 
 
-def batch_cold_solve(horizon, wq, wr, wt, lower, upper, refs, meas, wind, threads=1):
+def batch_cold_solve(horizon, wq, wr, wt, lower, upper, refs, meas, wind, threads=1,
+                     precision="double"):
     """refs [B][N+1][16], meas [B][13], wind [B][3] -> (u, status, iters, seconds)"""
-    refs, meas, wind = _f(refs), _f(meas), _f(wind)
+    refs, meas, wind = _f(refs, precision=precision), _f(meas, precision=precision), _f(wind, precision=precision)
     B = meas.shape[0]
     assert refs.shape == (B, horizon + 1, 16) and wind.shape == (B, 3)
-    u = np.zeros((B, 3))
+    u = np.zeros((B, 3), dtype=DTYPES[precision])
     status = np.zeros(B, dtype=np.int32)
     iters = np.zeros(B, dtype=np.int32)
-    secs = lib().port_batch_cold_solve(
-        horizon, B, threads, _dp(_f(wq, 12)), _dp(_f(wr, 3)), _dp(_f(wt, 12)),
-        _dp(_f(lower, 3)), _dp(_f(upper, 3)), _dp(refs), _dp(meas), _dp(wind),
+    secs = lib(precision).port_batch_cold_solve(
+        horizon, B, threads, _dp(_f(wq, 12, precision=precision)), _dp(_f(wr, 3, precision=precision)), _dp(_f(wt, 12, precision=precision)),
+        _dp(_f(lower, 3, precision=precision)), _dp(_f(upper, 3, precision=precision)), _dp(refs), _dp(meas), _dp(wind),
         _dp(u), _ip(status), _ip(iters))
     return u, status, iters, secs
 
 
-def batch_linearise(x, u, xnext, wind, lower, upper, threads=1):
+def batch_linearise(x, u, xnext, wind, lower, upper, threads=1, precision="double"):
     """[n][13], [n][3], [n][13], [n][3] -> (jac [n][180], res [n][12], seconds)"""
-    x, u, xnext, wind = _f(x), _f(u), _f(xnext), _f(wind)
+    x, u, xnext, wind = _f(x, precision=precision), _f(u, precision=precision), _f(xnext, precision=precision), _f(wind, precision=precision)
     n = x.shape[0]
-    jac, res = np.zeros((n, 180)), np.zeros((n, 12))
-    secs = lib().port_batch_linearise(n, threads, _dp(x), _dp(u), _dp(xnext), _dp(wind),
-                                      _dp(_f(lower, 3)), _dp(_f(upper, 3)), _dp(jac), _dp(res))
+    jac, res = np.zeros((n, 180), dtype=DTYPES[precision]), np.zeros((n, 12), dtype=DTYPES[precision])
+    secs = lib(precision).port_batch_linearise(n, threads, _dp(x), _dp(u), _dp(xnext), _dp(wind),
+                                      _dp(_f(lower, 3, precision=precision)), _dp(_f(upper, 3, precision=precision)), _dp(jac), _dp(res))
     return jac, res, secs

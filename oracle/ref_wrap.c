@@ -19,11 +19,12 @@
 #define REF_STAGE_REC 332
 
 unsigned ref_horizon(void) { return REF_N; }
+unsigned ref_real_bytes(void) { return (unsigned)sizeof(real_t); }
 unsigned ref_stage_rec(void) { return REF_STAGE_REC; }
 
 int ref_num_iter(void) { return ocp_qp_data.qpdata.log.numIter; }
 int ref_last_result(void) { return ocp_last_result ? 1 : 0; }
-double ref_alpha(void) { return ocp_qp_data.qpdata.alpha; }
+real_t ref_alpha(void) { return ocp_qp_data.qpdata.alpha; }
 int ref_line_search_iter(void) {
     return (int)ocp_qp_data.qpdata.log.itLog[0].numLineSearchIter;
 }
@@ -32,53 +33,53 @@ int ref_hessian_regularized(void) {
 }
 
 /* Direct access to the static model functions (cnmpc.c:320-667). */
-void ref_set_wind(const double *w) {
+void ref_set_wind(const real_t *w) {
     wind_velocity[0] = w[0]; wind_velocity[1] = w[1]; wind_velocity[2] = w[2];
 }
-void ref_x8_dynamics(double *out6, const double *state, const double *control) {
+void ref_x8_dynamics(real_t *out6, const real_t *state, const real_t *control) {
     _state_x8_dynamics(out6, state, control);
 }
-void ref_state_model(double *out13, const double *state, const double *control) {
+void ref_state_model(real_t *out13, const real_t *state, const real_t *control) {
     _state_model(out13, state, control);
 }
-void ref_rk4(double *out13, const double *state, const double *control,
-             double delta) {
+void ref_rk4(real_t *out13, const real_t *state, const real_t *control,
+             real_t delta) {
     _state_integrate_rk4(out13, state, control, delta);
 }
-void ref_state_to_delta(double *out12, const double *s1, const double *s2) {
+void ref_state_to_delta(real_t *out12, const real_t *s1, const real_t *s2) {
     _state_to_delta(out12, s1, s2);
 }
 /* Uses the control bounds currently held by the library (cnmpc.c:643-645). */
-void ref_solve_interval_ivp(const double *state, const double *control,
-                            const double *next_state, double *jac180,
-                            double *res12) {
+void ref_solve_interval_ivp(const real_t *state, const real_t *control,
+                            const real_t *next_state, real_t *jac180,
+                            real_t *res12) {
     _solve_interval_ivp(state, control, jac180, next_state, res12);
 }
 
-static double *put(double *o, const double *src, size_t n) {
-    memcpy(o, src, n * sizeof(double));
+static real_t *put(real_t *o, const real_t *src, size_t n) {
+    memcpy(o, src, n * sizeof(real_t));
     return o + n;
 }
 
-void ref_get_stage(unsigned k, double *o) {
+void ref_get_stage(unsigned k, real_t *o) {
     const interval_t *iv = ocp_qp_data.qpdata.intervals[k];
-    memset(o, 0, REF_STAGE_REC * sizeof(double));
+    memset(o, 0, REF_STAGE_REC * sizeof(real_t));
     size_t nv = iv->nV;
     if (k < REF_N) {
-        memcpy(o, iv->C.data, 180 * sizeof(double));
-        memcpy(o + 180, iv->c.data, 12 * sizeof(double));
+        memcpy(o, iv->C.data, 180 * sizeof(real_t));
+        memcpy(o + 180, iv->c.data, 12 * sizeof(real_t));
     }
-    memcpy(o + 192, iv->zLow.data, nv * sizeof(double));
-    memcpy(o + 207, iv->zUpp.data, nv * sizeof(double));
-    memcpy(o + 222, iv->q.data, nv * sizeof(double));
+    memcpy(o + 192, iv->zLow.data, nv * sizeof(real_t));
+    memcpy(o + 207, iv->zUpp.data, nv * sizeof(real_t));
+    memcpy(o + 222, iv->q.data, nv * sizeof(real_t));
     o[237] = iv->p;
-    memcpy(o + 238, iv->z.data, nv * sizeof(double));
-    memcpy(o + 253, iv->y.data, 2 * nv * sizeof(double));
-    memcpy(o + 283, iv->qpSolverClipping.qStep.data, nv * sizeof(double));
+    memcpy(o + 238, iv->z.data, nv * sizeof(real_t));
+    memcpy(o + 253, iv->y.data, 2 * nv * sizeof(real_t));
+    memcpy(o + 283, iv->qpSolverClipping.qStep.data, nv * sizeof(real_t));
     o[298] = iv->qpSolverClipping.pStep;
     memcpy(o + 299, iv->qpSolverClipping.zUnconstrained.data,
-           nv * sizeof(double));
-    memcpy(o + 314, iv->qpSolverClipping.dz.data, nv * sizeof(double));
+           nv * sizeof(real_t));
+    memcpy(o + 314, iv->qpSolverClipping.dz.data, nv * sizeof(real_t));
     /* 329..331 spare */
 }
 
@@ -89,7 +90,7 @@ unsigned ref_global_size(void) {
            13 * (REF_N + 1) + 3 * REF_N + 3;
 }
 
-void ref_get_global(double *o) {
+void ref_get_global(real_t *o) {
     const qpData_t *qp = &ocp_qp_data.qpdata;
     size_t k, i;
     o = put(o, qp->lambda.data, 12 * REF_N);
@@ -100,11 +101,11 @@ void ref_get_global(double *o) {
     for (k = 0; k <= REF_N; k++)
         for (i = 0; i < 15; i++)
             *o++ = (i < qp->intervals[k]->nV)
-                       ? (double)qp->log.itLog[0].ieqStatus[k][i] : 0.0;
+                       ? (real_t)qp->log.itLog[0].ieqStatus[k][i] : 0.0;
     for (k = 0; k <= REF_N; k++)
         for (i = 0; i < 15; i++)
             *o++ = (i < qp->intervals[k]->nV)
-                       ? (double)qp->log.itLog[0].prevIeqStatus[k][i] : 0.0;
+                       ? (real_t)qp->log.itLog[0].prevIeqStatus[k][i] : 0.0;
     o = put(o, ocp_state_reference, 13 * (REF_N + 1));
     o = put(o, ocp_control_reference, 3 * REF_N);
     o = put(o, ocp_control_value, 3);

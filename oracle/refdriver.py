@@ -33,25 +33,27 @@ def global_fields(n):
     return out, off
 
 
-def ref_path(n=100):
-    return os.path.join(HERE, "_ref", "libref_n%d.so" % n)
+def ref_path(n=100, precision="double"):
+    tag = "n%d" % n if precision == "double" else "f32_n%d" % n
+    return os.path.join(HERE, "_ref", "libref_%s.so" % tag)
 
 
-def have_ref(n=100):
-    return os.path.exists(ref_path(n))
-
-
-def _dp(a):
-    return a.ctypes.data_as(C.POINTER(C.c_double))
+def have_ref(n=100, precision="double"):
+    return os.path.exists(ref_path(n, precision))
 
 
 class Ref:
     """One private instance of the reference controller."""
 
-    def __init__(self, n=100):
-        src = ref_path(n)
+    def __init__(self, n=100, precision="double"):
+        """precision "double": the fp64 configuration; "float": the reference's
+        shipped single-precision configuration.  All arrays in and out are
+        numpy arrays of that type."""
+        src = ref_path(n, precision)
         if not os.path.exists(src):
-            raise FileNotFoundError(src + " (run `make -C oracle ref N=%d`)" % n)
+            raise FileNotFoundError(src + " (run `make -C oracle ref N=%d PREC=%s`)" % (n, precision))
+        self.dtype = np.float64 if precision == "double" else np.float32
+        self.ctype = C.c_double if precision == "double" else C.c_float
         fd, self._tmp = tempfile.mkstemp(suffix=".so", prefix="libref_")
         os.close(fd)
         shutil.copyfile(src, self._tmp)
@@ -59,7 +61,9 @@ class Ref:
         os.unlink(self._tmp)
         self.N = n
         assert lib.ref_horizon() == n
-        dp = C.POINTER(C.c_double)
+        assert lib.ref_real_bytes() == np.dtype(self.dtype).itemsize
+        dp = C.POINTER(self.ctype)
+        real = self.ctype
         for name in ("nmpc_feedback_step", "nmpc_update_horizon",
                      "nmpc_set_state_weights", "nmpc_set_control_weights",
                      "nmpc_set_terminal_weights", "nmpc_set_lower_control_bound",
@@ -70,14 +74,14 @@ class Ref:
         lib.nmpc_get_controls.restype = C.c_int
         lib.nmpc_set_reference_point.argtypes = [dp, C.c_uint32]
         lib.nmpc_set_reference_point.restype = None
-        lib.nmpc_set_wind_velocity.argtypes = [C.c_double] * 3
+        lib.nmpc_set_wind_velocity.argtypes = [real] * 3
         lib.nmpc_set_wind_velocity.restype = None
         lib.nmpc_init.restype = None
         lib.nmpc_preparation_step.restype = None
-        lib.ref_alpha.restype = C.c_double
+        lib.ref_alpha.restype = real
         lib.ref_get_stage.argtypes = [C.c_uint, dp]
         lib.ref_get_global.argtypes = [dp]
-        lib.ref_rk4.argtypes = [dp, dp, dp, C.c_double]
+        lib.ref_rk4.argtypes = [dp, dp, dp, real]
         for name, na in (("ref_set_wind", 1), ("ref_x8_dynamics", 3),
                          ("ref_state_model", 3), ("ref_state_to_delta", 3),
                          ("ref_solve_interval_ivp", 5)):
@@ -86,9 +90,19 @@ class Ref:
         self.gfields, self.gsize = global_fields(n)
         assert lib.ref_global_size() == self.gsize
 
+    def _a(self, v, n=None):
+        a = np.ascontiguousarray(v, dtype=self.dtype)
+        if n is not None:
+            assert a.shape == (n,), (a.shape, n)
+        return a
+
+    def _p(self, a):
+        assert a.dtype == self.dtype
+        return a.ctypes.data_as(C.POINTER(self.ctype))
+
     # -- controller API (c/cnmpc.h) ------------------------------------
     def setup(self, state_w, control_w, terminal_w, upper, lower):
-        f = lambda v: _dp(np.ascontiguousarray(v, dtype=np.float64))
+        f = lambda v: self._p(self._a(v))
         self.lib.nmpc_set_state_weights(f(state_w))
         self.lib.nmpc_set_control_weights(f(control_w))
         self.lib.nmpc_set_terminal_weights(f(terminal_w))
@@ -99,41 +113,35 @@ class Ref:
         self.lib.nmpc_init()
 
     def set_reference(self, point, i):
-        p = np.ascontiguousarray(point, dtype=np.float64)
-        assert p.shape == (16,)
-        self.lib.nmpc_set_reference_point(_dp(p), i)
+        self.lib.nmpc_set_reference_point(self._p(self._a(point, 16)), i)
 
     def set_wind(self, w):
         self.lib.nmpc_set_wind_velocity(float(w[0]), float(w[1]), float(w[2]))
 
     def feedback(self, meas):
-        m = np.ascontiguousarray(meas, dtype=np.float64)
-        assert m.shape == (13,)
-        self.lib.nmpc_feedback_step(_dp(m))
+        self.lib.nmpc_feedback_step(self._p(self._a(meas, 13)))
 
     def controls(self):
-        u = np.zeros(3)
-        st = self.lib.nmpc_get_controls(_dp(u))
+        u = np.zeros(3, dtype=self.dtype)
+        st = self.lib.nmpc_get_controls(self._p(u))
         return u, st
 
     def update_horizon(self, point):
-        p = np.ascontiguousarray(point, dtype=np.float64)
-        assert p.shape == (16,)
-        self.lib.nmpc_update_horizon(_dp(p))
+        self.lib.nmpc_update_horizon(self._p(self._a(point, 16)))
 
     def num_iter(self):
         return self.lib.ref_num_iter()
 
     # -- internals ------------------------------------------------------
     def stages(self):
-        out = np.zeros((self.N + 1, STAGE_REC))
+        out = np.zeros((self.N + 1, STAGE_REC), dtype=self.dtype)
         for k in range(self.N + 1):
-            self.lib.ref_get_stage(k, _dp(out[k]))
+            self.lib.ref_get_stage(k, self._p(out[k]))
         return out
 
     def globals_(self):
-        out = np.zeros(self.gsize)
-        self.lib.ref_get_global(_dp(out))
+        out = np.zeros(self.gsize, dtype=self.dtype)
+        self.lib.ref_get_global(self._p(out))
         return out
 
     def gfield(self, g, name):
@@ -142,41 +150,41 @@ class Ref:
 
     # -- model functions ------------------------------------------------
     def x8_dynamics(self, x, u, wind):
-        x, u, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, u, wind))
-        out = np.zeros(6)
-        self.lib.ref_set_wind(_dp(w))
-        self.lib.ref_x8_dynamics(_dp(out), _dp(x), _dp(u))
+        x, u, w = (self._a(a) for a in (x, u, wind))
+        out = np.zeros(6, dtype=self.dtype)
+        self.lib.ref_set_wind(self._p(w))
+        self.lib.ref_x8_dynamics(self._p(out), self._p(x), self._p(u))
         return out
 
     def state_model(self, x, u, wind):
-        x, u, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, u, wind))
-        out = np.zeros(13)
-        self.lib.ref_set_wind(_dp(w))
-        self.lib.ref_state_model(_dp(out), _dp(x), _dp(u))
+        x, u, w = (self._a(a) for a in (x, u, wind))
+        out = np.zeros(13, dtype=self.dtype)
+        self.lib.ref_set_wind(self._p(w))
+        self.lib.ref_state_model(self._p(out), self._p(x), self._p(u))
         return out
 
     def rk4(self, x, u, wind, delta=1.0 / 50.0):
-        x, u, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, u, wind))
-        out = np.zeros(13)
-        self.lib.ref_set_wind(_dp(w))
-        self.lib.ref_rk4(_dp(out), _dp(x), _dp(u), delta)
+        x, u, w = (self._a(a) for a in (x, u, wind))
+        out = np.zeros(13, dtype=self.dtype)
+        self.lib.ref_set_wind(self._p(w))
+        self.lib.ref_rk4(self._p(out), self._p(x), self._p(u), delta)
         return out
 
     def state_to_delta(self, s1, s2):
-        s1, s2 = (np.ascontiguousarray(a, dtype=np.float64) for a in (s1, s2))
-        out = np.zeros(12)
-        self.lib.ref_state_to_delta(_dp(out), _dp(s1), _dp(s2))
+        s1, s2 = (self._a(a) for a in (s1, s2))
+        out = np.zeros(12, dtype=self.dtype)
+        self.lib.ref_state_to_delta(self._p(out), self._p(s1), self._p(s2))
         return out
 
     def linearise(self, x, u, xnext, wind, lower, upper):
         """C (12x15 row-major) and c for one stage; sets the library's bounds."""
-        x, u, xn, w = (np.ascontiguousarray(a, dtype=np.float64)
+        x, u, xn, w = (self._a(a)
                        for a in (x, u, xnext, wind))
-        lo = np.ascontiguousarray(lower, dtype=np.float64)
-        up = np.ascontiguousarray(upper, dtype=np.float64)
-        self.lib.nmpc_set_lower_control_bound(_dp(lo))
-        self.lib.nmpc_set_upper_control_bound(_dp(up))
-        self.lib.ref_set_wind(_dp(w))
-        jac, res = np.zeros(180), np.zeros(12)
-        self.lib.ref_solve_interval_ivp(_dp(x), _dp(u), _dp(xn), _dp(jac), _dp(res))
+        lo = self._a(lower)
+        up = self._a(upper)
+        self.lib.nmpc_set_lower_control_bound(self._p(lo))
+        self.lib.nmpc_set_upper_control_bound(self._p(up))
+        self.lib.ref_set_wind(self._p(w))
+        jac, res = np.zeros(180, dtype=self.dtype), np.zeros(12, dtype=self.dtype)
+        self.lib.ref_solve_interval_ivp(self._p(x), self._p(u), self._p(xn), self._p(jac), self._p(res))
         return jac, res

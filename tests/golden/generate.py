@@ -4,8 +4,10 @@ Drives the reference's own pure-C controller, compiled in fp64 by
 `make -C oracle ref N=<horizon>` into oracle/_ref/, on seeded inputs and stores
 inputs plus the reference's outputs as compressed .npz fixtures next to this
 file.  The fixtures are data only; nothing of the reference's source travels.
+The *_f32 fixtures come from the reference in its shipped single-precision
+configuration (`make -C oracle ref PREC=float`); their arrays are float32.
 
-    python tests/golden/generate.py
+    python tests/golden/generate.py [part ...]
 """
 import os
 import sys
@@ -27,43 +29,43 @@ def save(name, **arrays):
     print("%-28s %7.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024.0))
 
 
-def gen_model():
+def gen_model(precision="double", name="model"):
     rng = np.random.default_rng(20131118)
-    r = Ref(100)
+    r = Ref(100, precision)
     n = 2048
-    x, u, w = S.random_states(n, rng)
+    x, u, w = (a.astype(r.dtype) for a in S.random_states(n, rng))
     acc = np.stack([r.x8_dynamics(x[i], u[i], w[i]) for i in range(n)])
     xdot = np.stack([r.state_model(x[i], u[i], w[i]) for i in range(n)])
     xplus = np.stack([r.rk4(x[i], u[i], w[i]) for i in range(n)])
     # state difference, including pairs whose error quaternion has w < 0
     s1 = x.copy()
     s2 = np.roll(x, 7, axis=0).copy()
-    s2[::3, 6:10] = -s1[::3, 6:10] + rng.normal(0, 0.05, (len(s1[::3]), 4))
+    s2[::3, 6:10] = -s1[::3, 6:10] + rng.normal(0, 0.05, (len(s1[::3]), 4)).astype(r.dtype)
     delta = np.stack([r.state_to_delta(s1[i], s2[i]) for i in range(n)])
-    save("model", x=x, u=u, wind=w, accel=acc, xdot=xdot, xplus=xplus,
+    save(name, x=x, u=u, wind=w, accel=acc, xdot=xdot, xplus=xplus,
          s1=s1, s2=s2, delta=delta)
 
 
-def gen_linearise():
+def gen_linearise(precision="double", name="linearise"):
     rng = np.random.default_rng(42)
-    r = Ref(100)
+    r = Ref(100, precision)
     n = 384
-    x, u, w = S.random_states(n, rng)
+    x, u, w = (a.astype(r.dtype) for a in S.random_states(n, rng))
     xn = np.stack([r.rk4(x[i], u[i], w[i]) for i in range(n)])
-    xn += rng.normal(0, 1e-3, xn.shape)
+    xn += rng.normal(0, 1e-3, xn.shape).astype(r.dtype)
     xn[::5] = np.roll(x, 3, axis=0)[::5]
-    lower = np.array([0.0, -0.1, 0.05])
-    upper = np.array([1.0, 0.9, 1.3])
-    jac = np.zeros((n, 180))
-    res = np.zeros((n, 12))
+    lower = np.array([0.0, -0.1, 0.05], dtype=r.dtype)
+    upper = np.array([1.0, 0.9, 1.3], dtype=r.dtype)
+    jac = np.zeros((n, 180), dtype=r.dtype)
+    res = np.zeros((n, 12), dtype=r.dtype)
     for i in range(n):
         jac[i], res[i] = r.linearise(x[i], u[i], xn[i], w[i], lower, upper)
-    save("linearise", x=x, u=u, xnext=xn, wind=w, lower=lower, upper=upper,
+    save(name, x=x, u=u, xnext=xn, wind=w, lower=lower, upper=upper,
          jac=jac, res=res)
 
 
 def run_sequence(name, horizon, refs, meas, wind_schedule, steps, weights=None,
-                 bounds=None, dump=False):
+                 bounds=None, dump=False, precision="double"):
     """wind_schedule: list of (first_step, wind3).  The wind set before loading
     the horizon is wind_schedule[0]."""
     cfg = S.setup_args()
@@ -71,23 +73,25 @@ def run_sequence(name, horizon, refs, meas, wind_schedule, steps, weights=None,
         cfg.update(weights)
     if bounds:
         cfg.update(bounds)
-    r = Ref(horizon)
+    r = Ref(horizon, precision)
+    dt = r.dtype
+    refs, meas = np.asarray(refs, dtype=dt), np.asarray(meas, dtype=dt)
     r.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
             cfg["upper_control_bound"], cfg["lower_control_bound"])
     r.init()
-    winds = np.zeros((steps, 3))
-    cur = np.asarray(wind_schedule[0][1], dtype=np.float64)
-    sched = {int(s): np.asarray(w, dtype=np.float64) for s, w in wind_schedule}
+    winds = np.zeros((steps, 3), dtype=dt)
+    cur = np.asarray(wind_schedule[0][1], dtype=dt)
+    sched = {int(s): np.asarray(w, dtype=dt) for s, w in wind_schedule}
     r.set_wind(cur)
     for i in range(horizon + 1):
         r.set_reference(refs[i], i)
     loaded = r.stages()[:, :192].copy() if dump else None     # C and c after loading
-    u = np.zeros((steps, 3))
+    u = np.zeros((steps, 3), dtype=dt)
     status = np.zeros(steps, dtype=np.int32)
     iters = np.zeros(steps, dtype=np.int32)
     ls = np.zeros(steps, dtype=np.int32)
-    alpha = np.zeros(steps)
-    z0 = np.zeros((steps, 15))
+    alpha = np.zeros(steps, dtype=dt)
+    z0 = np.zeros((steps, 15), dtype=dt)
     lam_norm = np.zeros(steps)
     for k in range(steps):
         if k in sched:
@@ -105,11 +109,11 @@ def run_sequence(name, horizon, refs, meas, wind_schedule, steps, weights=None,
         r.update_horizon(refs[horizon + 1 + k])
     out = dict(horizon=np.int32(horizon), refs=np.asarray(refs[:horizon + 1 + steps]),
                meas=np.asarray(meas[:steps]), winds=winds,
-               state_weights=np.asarray(cfg["state_weights"], dtype=np.float64),
-               control_weights=np.asarray(cfg["control_weights"], dtype=np.float64),
-               terminal_weights=np.asarray(cfg["terminal_weights"], dtype=np.float64),
-               upper=np.asarray(cfg["upper_control_bound"], dtype=np.float64),
-               lower=np.asarray(cfg["lower_control_bound"], dtype=np.float64),
+               state_weights=np.asarray(cfg["state_weights"], dtype=dt),
+               control_weights=np.asarray(cfg["control_weights"], dtype=dt),
+               terminal_weights=np.asarray(cfg["terminal_weights"], dtype=dt),
+               upper=np.asarray(cfg["upper_control_bound"], dtype=dt),
+               lower=np.asarray(cfg["lower_control_bound"], dtype=dt),
                u=u, status=status, iters=iters, ls_iters=ls, alpha=alpha, z0=z0,
                lam_norm=lam_norm)
     if dump:
@@ -168,6 +172,31 @@ def gen_indefinite():
                  weights=dict(state_weights=[1, 1, 1, -1, -1, -1, 1, 1, 1, 1, 1, 1]), dump=True)
 
 
+def gen_single_precision():
+    """The reference in its shipped single-precision configuration."""
+    gen_model("float", "model_f32")
+    gen_linearise("float", "linearise_f32")
+    N = 100
+    steps = 8
+    refs = S.straight_reference(N + 1 + steps)
+    meas = np.stack([S.straight_measurement(refs[k]) for k in range(steps)])
+    run_sequence("seq_straight_f32", N, refs, meas, [(0, [0, 0, 0])], steps, dump=True,
+                 precision="float")
+    steps = 30
+    d = S.make_batch(4, N, extra_steps=steps, seed=5, turn_start=(0.3, 3.0))
+    for b in range(4):
+        w = d["wind"][b]
+        sched = [(0, w), (10, 0.5 * w), (20, [w[1], -w[0], 0.3 * w[2]])]
+        run_sequence("seq_turn%d_f32" % b, N, d["refs"][b], d["meas"][b], sched, steps,
+                     dump=(b == 0), precision="float")
+    run_sequence("seq_bound_f32", N, d["refs"][1], d["meas"][1], [(0, d["wind"][1])], 12,
+                 bounds=dict(upper_control_bound=[0.62, 0.55, 0.55],
+                             lower_control_bound=[0.4, 0.45, 0.45]), dump=True, precision="float")
+    run_sequence("seq_identity_f32", N, d["refs"][2], d["meas"][2], [(0, d["wind"][2])], 8,
+                 weights=dict(state_weights=[1] * 12, control_weights=[1] * 3,
+                              terminal_weights=[1] * 12), precision="float")
+
+
 def gen_long_horizon():
     from refdriver import have_ref
     if not have_ref(500):
@@ -183,6 +212,7 @@ def gen_long_horizon():
 if __name__ == "__main__":
     import sys
     parts = dict(model=gen_model, linearise=gen_linearise, sequences=gen_sequences,
-                 indefinite=gen_indefinite, long_horizon=gen_long_horizon)
+                 indefinite=gen_indefinite, long_horizon=gen_long_horizon,
+                 single_precision=gen_single_precision)
     for name in (sys.argv[1:] or list(parts)):      # no argument: everything
         parts[name]()

@@ -11,6 +11,16 @@ SEQUENCES = ["seq_straight", "seq_turn0", "seq_turn1", "seq_turn2", "seq_turn3",
              "seq_linesearch", "seq_exact", "seq_indefinite", "seq_n500_0", "seq_n500_1"]
 
 
+# the same from the reference in its shipped single-precision configuration
+SEQUENCES_F32 = ["seq_straight_f32", "seq_turn0_f32", "seq_turn1_f32", "seq_turn2_f32",
+                 "seq_turn3_f32", "seq_bound_f32", "seq_identity_f32"]
+
+
+def precision_of(g):
+    """"float" for a fixture of the single-precision reference, else "double"."""
+    return "float" if g["u"].dtype == np.float32 else "double"
+
+
 def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
@@ -27,15 +37,16 @@ def drive_port(g, dump=False):
     N = int(g["horizon"])
     steps = len(g["u"])
     c = config_of(g)
-    p = P.Port(N)
+    p = P.Port(N, precision_of(g))
+    dt = g["u"].dtype
     p.setup(c["state_weights"], c["control_weights"], c["terminal_weights"],
             c["upper_control_bound"], c["lower_control_bound"])
     p.init()
     p.set_wind(g["winds"][0])
     for i in range(N + 1):
         p.set_reference(g["refs"][i], i)
-    out = dict(u=np.zeros((steps, 3)), status=np.zeros(steps, np.int32),
-               iters=np.zeros(steps, np.int32), z0=np.zeros((steps, 15)))
+    out = dict(u=np.zeros((steps, 3), dt), status=np.zeros(steps, np.int32),
+               iters=np.zeros(steps, np.int32), z0=np.zeros((steps, 15), dt))
     if dump:
         out["loaded_Cc"] = p.stages()[:, :192].copy()
     for k in range(steps):

@@ -4,18 +4,20 @@ the compiled reference itself where oracle/_ref is present."""
 import numpy as np
 import pytest
 
-from helpers import SEQUENCES, assert_same, drive_port, golden
+from helpers import SEQUENCES, SEQUENCES_F32, assert_same, drive_port, golden, precision_of
 
 
-def test_model_functions(port_built):
+@pytest.mark.parametrize("name", ["model", "model_f32"])
+def test_model_functions(port_built, name):
     P = port_built
-    g = golden("model")
+    g = golden(name)
+    pr = precision_of(g)
     n = len(g["x"])
     for i in range(n):
-        assert_same(P.x8_dynamics(g["x"][i], g["u"][i], g["wind"][i]), g["accel"][i], "accel[%d]" % i)
-        assert_same(P.state_model(g["x"][i], g["u"][i], g["wind"][i]), g["xdot"][i], "xdot[%d]" % i)
-        assert_same(P.rk4(g["x"][i], g["u"][i], g["wind"][i]), g["xplus"][i], "xplus[%d]" % i)
-        assert_same(P.state_to_delta(g["s1"][i], g["s2"][i]), g["delta"][i], "delta[%d]" % i)
+        assert_same(P.x8_dynamics(g["x"][i], g["u"][i], g["wind"][i], precision=pr), g["accel"][i], "accel[%d]" % i)
+        assert_same(P.state_model(g["x"][i], g["u"][i], g["wind"][i], precision=pr), g["xdot"][i], "xdot[%d]" % i)
+        assert_same(P.rk4(g["x"][i], g["u"][i], g["wind"][i], precision=pr), g["xplus"][i], "xplus[%d]" % i)
+        assert_same(P.state_to_delta(g["s1"][i], g["s2"][i], precision=pr), g["delta"][i], "delta[%d]" % i)
 
 
 def test_model_covers_branches():
@@ -32,17 +34,18 @@ def test_model_covers_branches():
     assert (dots < 0).any() and (dots > 0).any()
 
 
-def test_linearise(port_built):
+@pytest.mark.parametrize("name", ["linearise", "linearise_f32"])
+def test_linearise(port_built, name):
     P = port_built
-    g = golden("linearise")
+    g = golden(name)
     for i in range(len(g["x"])):
         jac, res = P.linearise(g["x"][i], g["u"][i], g["xnext"][i], g["wind"][i],
-                               g["lower"], g["upper"])
+                               g["lower"], g["upper"], precision=precision_of(g))
         assert_same(jac, g["jac"][i], "jac[%d]" % i)
         assert_same(res, g["res"][i], "res[%d]" % i)
 
 
-@pytest.mark.parametrize("name", SEQUENCES)
+@pytest.mark.parametrize("name", SEQUENCES + SEQUENCES_F32)
 def test_sequences(port_built, name):
     g = golden(name)
     dump = "final_stages" in g
@@ -72,11 +75,12 @@ def test_known_answer_straight():
         assert g["iters"][k] == it
 
 
-def test_port_against_compiled_reference(port_built):
+@pytest.mark.parametrize("precision", ["double", "float"])
+def test_port_against_compiled_reference(port_built, precision):
     """Where the reference build exists (this container), replay fresh random
     sequences through both and compare every stored quantity."""
     import refdriver
-    if not refdriver.have_ref(100):
+    if not refdriver.have_ref(100, precision):
         pytest.skip("oracle/_ref not built (reference tree absent)")
     from nmpc_amd import synthetic as S
     P = port_built
@@ -84,7 +88,7 @@ def test_port_against_compiled_reference(port_built):
     d = S.make_batch(3, N, extra_steps=steps, seed=77, turn_start=(0.3, 3.0))
     cfg = S.setup_args()
     for b in range(3):
-        r, p = refdriver.Ref(N), P.Port(N)
+        r, p = refdriver.Ref(N, precision), P.Port(N, precision)
         for o in (r, p):
             o.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
                     cfg["upper_control_bound"], cfg["lower_control_bound"])
