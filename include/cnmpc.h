@@ -24,7 +24,12 @@
 
 #include <stdint.h>
 
+/* real_t is double; a build with -DNMPC_SINGLE_PRECISION (libcnmpc_f32.so) is
+ * the reference's shipped single-precision configuration (include/config.h:27-28,
+ * c/cnmpc.h:29-33) and reports NMPC_PRECISION_FLOAT. */
+#ifndef NMPC_SINGLE_PRECISION
 #define NMPC_DOUBLE_PRECISION
+#endif
 #define NMPC_CONTROL_DIM 3
 #define NMPC_STATE_DIM 13
 #define NMPC_DELTA_DIM (NMPC_STATE_DIM - 1)
@@ -33,7 +38,11 @@
 #define OCP_HORIZON_LENGTH 100
 #define OCP_STEP_LENGTH ((real_t)(1.0 / 50.0))
 
+#ifdef NMPC_SINGLE_PRECISION
+typedef float real_t;
+#else
 typedef double real_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {

@@ -112,13 +112,12 @@ def init(implementation="c"):
         raise NameError(
             "Unknown NMPC implementation: %s (options are 'c', 'c66x')" % implementation)
     _cnmpc = _lib.load()
-    precision = _cnmpc.nmpc_config_get_precision()
-    if precision != NMPC_PRECISION_DOUBLE:
-        raise NmpcError("libcnmpc.so reports precision %d, expected double" % precision)
-    _REAL_T = _lib.REAL
+    # as the reference module does (__init__.py:123-124): the ctypes real type
+    # follows the precision the library reports
+    _REAL_T = _cnmpc.real
     _CONTROL_DIM = _cnmpc.nmpc_config_get_control_dim()
     _STATE_DIM = _cnmpc.nmpc_config_get_state_dim()
     HORIZON_LENGTH = _cnmpc.nmpc_config_get_horizon_length()
     STEP_LENGTH = _cnmpc.nmpc_config_get_step_length()
-    state = _State()
+    state = _cnmpc.State()
     _cnmpc.nmpc_fixedwingdynamics_get_state(pointer(state))

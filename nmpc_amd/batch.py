@@ -18,27 +18,28 @@ def _is_torch(x):
 
 
 class _Arg:
-    """Pointer + keep-alive for a [..] float64 input."""
+    """Pointer + keep-alive for a [..] input of the library's real type."""
 
-    def __init__(self, x, shape):
+    def __init__(self, x, shape, dtype=np.float64):
         if _is_torch(x):
             import torch
-            if x.dtype != torch.float64 or not x.is_contiguous():
-                raise TypeError("device inputs must be contiguous float64 tensors")
+            want = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
+            if x.dtype != want or not x.is_contiguous():
+                raise TypeError("device inputs must be contiguous %s tensors" % np.dtype(dtype).name)
             if tuple(x.shape) != tuple(shape):
                 raise ValueError("expected shape %s, got %s" % (shape, tuple(x.shape)))
             self.keep = x
             self.ptr = C.c_void_p(x.data_ptr())
         else:
-            a = np.ascontiguousarray(x, dtype=np.float64)
+            a = np.ascontiguousarray(x, dtype=dtype)
             if a.shape != tuple(shape):
                 raise ValueError("expected shape %s, got %s" % (shape, a.shape))
             self.keep = a
             self.ptr = C.c_void_p(a.ctypes.data)
 
 
-def _vec(v, n):
-    a = np.ascontiguousarray(v, dtype=np.float64)
+def _vec(v, n, dtype=np.float64):
+    a = np.ascontiguousarray(v, dtype=dtype)
     if a.shape != (n,):
         raise ValueError("expected %d values" % n)
     return a
@@ -47,6 +48,7 @@ def _vec(v, n):
 class Batch:
     def __init__(self, instances, horizon=100, device=0, stream=None):
         self.lib = _lib.load()
+        self.dtype = np.dtype(self.lib.np_real)     # float64, or float32 for libcnmpc_f32.so
         self.B, self.N = int(instances), int(horizon)
         h = C.c_void_p()
         _lib.check(self.lib, self.lib.nmpc_batch_create(
@@ -75,7 +77,7 @@ class Batch:
         batch on its own stream is not ordered behind the torch stream that
         produced the tensor, so that stream is drained first (pass torch's stream
         to Batch() to avoid the wait)."""
-        a = _Arg(x, shape)
+        a = _Arg(x, shape, self.dtype)
         if _is_torch(x):
             if self._own_stream:
                 import torch
@@ -88,7 +90,8 @@ class Batch:
     # -- configuration -------------------------------------------------
     def setup(self, state_weights, control_weights, terminal_weights,
               upper_control_bound, lower_control_bound):
-        dp = lambda a: a.ctypes.data_as(_lib.PREAL)
+        dp = lambda a: a.ctypes.data_as(self.lib.preal)
+        _vec = lambda v, n: globals()["_vec"](v, n, self.dtype)
         self._ck(self.lib.nmpc_batch_set_state_weights(self.h, dp(_vec(state_weights, 12))))
         self._ck(self.lib.nmpc_batch_set_control_weights(self.h, dp(_vec(control_weights, 3))))
         self._ck(self.lib.nmpc_batch_set_terminal_weights(self.h, dp(_vec(terminal_weights, 12))))
@@ -153,7 +156,7 @@ class Batch:
 
     def get_controls(self):
         """-> (controls [B][3], status [B] (0 ok / 1 infeasible), iterations [B])"""
-        u = np.zeros((self.B, 3))
+        u = np.zeros((self.B, 3), dtype=self.dtype)
         st = np.zeros(self.B, dtype=np.int32)
         it = np.zeros(self.B, dtype=np.int32)
         self._ck(self.lib.nmpc_batch_get_controls(
@@ -179,7 +182,7 @@ class Batch:
         self._ck(self.lib.nmpc_batch_plant_set_state(self.h, a.ptr))
 
     def plant_state(self):
-        x = np.zeros((self.B, 13))
+        x = np.zeros((self.B, 13), dtype=self.dtype)
         self._ck(self.lib.nmpc_batch_plant_get_state(self.h, x.ctypes.data_as(C.c_void_p)))
         return x
 
@@ -204,20 +207,20 @@ class Batch:
 
     # -- introspection ---------------------------------------------------
     def stages(self, instance):
-        out = np.zeros((self.N + 1, 332))
+        out = np.zeros((self.N + 1, 332), dtype=self.dtype)
         for k in range(self.N + 1):
             self._ck(self.lib.nmpc_batch_get_stage(
-                self.h, instance, k, out[k].ctypes.data_as(_lib.PREAL)))
+                self.h, instance, k, out[k].ctypes.data_as(self.lib.preal)))
         return out
 
     def globals_(self, instance):
-        out = np.zeros(self.lib.nmpc_batch_global_size(self.h))
-        self._ck(self.lib.nmpc_batch_get_global(self.h, instance, out.ctypes.data_as(_lib.PREAL)))
+        out = np.zeros(self.lib.nmpc_batch_global_size(self.h), dtype=self.dtype)
+        self._ck(self.lib.nmpc_batch_get_global(self.h, instance, out.ctypes.data_as(self.lib.preal)))
         return out
 
     def solver_info(self, instance):
         info = (C.c_int32 * 6)()
-        alpha = C.c_double()
+        alpha = self.lib.real()
         self._ck(self.lib.nmpc_batch_get_solver_info(self.h, instance, info, C.byref(alpha)))
         keys = ("status", "num_iter", "last_change", "regularized", "ls_iter", "last_result")
         d = dict(zip(keys, list(info)))
@@ -243,36 +246,38 @@ class Batch:
         return out
 
 
-def _ptr(x):
+def _ptr(x, dtype=np.float64):
     if _is_torch(x):
         return C.c_void_p(x.data_ptr()), x
-    a = np.ascontiguousarray(x, dtype=np.float64)
+    a = np.ascontiguousarray(x, dtype=dtype)
     return C.c_void_p(a.ctypes.data), a
 
 
 def linearise_samples(x, u, x_next, wind, lower, upper, device=0, out=None):
     """Stage linearisation of n independent samples -> (jac [n][180], res [n][12])."""
     lib = _lib.load()
+    dt = np.dtype(lib.np_real)
     n = int(x.shape[0])
-    px, kx = _ptr(x); pu, ku = _ptr(u); pn, kn = _ptr(x_next); pw, kw = _ptr(wind)
+    px, kx = _ptr(x, dt); pu, ku = _ptr(u, dt); pn, kn = _ptr(x_next, dt); pw, kw = _ptr(wind, dt)
     if out is None:
-        jac, res = np.zeros((n, 180)), np.zeros((n, 12))
+        jac, res = np.zeros((n, 180), dtype=dt), np.zeros((n, 12), dtype=dt)
     else:
         jac, res = out
     pj, _ = (_ptr(jac) if _is_torch(jac) else (C.c_void_p(jac.ctypes.data), jac))
     pr, _ = (_ptr(res) if _is_torch(res) else (C.c_void_p(res.ctypes.data), res))
-    lo, up = _vec(lower, 3), _vec(upper, 3)
+    lo, up = _vec(lower, 3, dt), _vec(upper, 3, dt)
     _lib.check(lib, lib.nmpc_linearise_samples(
-        int(device), None, n, px, pu, pn, pw, lo.ctypes.data_as(_lib.PREAL),
-        up.ctypes.data_as(_lib.PREAL), pj, pr))
+        int(device), None, n, px, pu, pn, pw, lo.ctypes.data_as(lib.preal),
+        up.ctypes.data_as(lib.preal), pj, pr))
     return jac, res
 
 
 def rk4_samples(x, u, wind, delta=1.0 / 50.0, device=0, out=None):
     lib = _lib.load()
+    dt = np.dtype(lib.np_real)
     n = int(x.shape[0])
-    px, kx = _ptr(x); pu, ku = _ptr(u); pw, kw = _ptr(wind)
-    o = np.zeros((n, 13)) if out is None else out
+    px, kx = _ptr(x, dt); pu, ku = _ptr(u, dt); pw, kw = _ptr(wind, dt)
+    o = np.zeros((n, 13), dtype=dt) if out is None else out
     po = C.c_void_p(o.data_ptr()) if _is_torch(o) else C.c_void_p(o.ctypes.data)
     _lib.check(lib, lib.nmpc_rk4_samples(int(device), None, n, px, pu, pw, float(delta), po))
     return o

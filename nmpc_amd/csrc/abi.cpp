@@ -58,7 +58,7 @@ bool is_device_pointer(const void* p) {
 // A diagonal weight block within 1e-15 of the identity carries no data in the
 // reference's QP solver and behaves as exact ones
 // (ccs-c66x/qpDUNES/utils.c:106-117, setup_qp.c:229-258).
-bool is_identity(const double* w, int n) {
+bool is_identity(const real_t* w, int n) {
     for (int i = 0; i < n; i++)
         if (std::fabs(w[i] - 1.0) > 1e-15) return false;
     return true;
@@ -92,8 +92,8 @@ struct nmpc_batch {
     void* arena = nullptr;
     size_t arena_bytes = 0;
     size_t reset_bytes = 0;     // leading part of the arena that nmpc_batch_reset clears
-    double wq[12], wr[3], wt[12], lb[3], ub[3];
-    double init_lb[3], init_ub[3];      // control bounds as nmpc_batch_init saw them
+    real_t wq[12], wr[3], wt[12], lb[3], ub[3];
+    real_t init_lb[3], init_ub[3];      // control bounds as nmpc_batch_init saw them
     bool initialised = false;
     // Real-time-iteration preparation (nmpc_batch_set_rti): fresh[k] != 0 while
     // horizon position k has been linearised about the reference since the last
@@ -115,8 +115,8 @@ struct nmpc_batch {
     // looked at; clears happen only where an earlier reader turns up.
     bool stage_zero_pending = false;    // zLow, zUpp, q, z, qStep, zUnc, dz, tmp, y
     bool zy_zero_pending = false;       // z, y only (after nmpc_batch_init)
-    double* plant = nullptr;    // [B][13] simulated vehicle states (nmpc_batch_plant_*)
-    double* plant_next = nullptr;   // output of the next roll-forward step, then swapped
+    real_t* plant = nullptr;    // [B][13] simulated vehicle states (nmpc_batch_plant_*)
+    real_t* plant_next = nullptr;   // output of the next roll-forward step, then swapped
     bool profiling = false;
     unsigned profile_kinds = ~0u;   // bit k: launches of kernel id k are timed
     std::vector<TimedLaunch> pending;
@@ -212,7 +212,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // Carries out the postponed clears of the stage vectors.
 int materialise_stage_vectors(nmpc_batch* b) {
     const BatchView& v = b->v;
-    const size_t vec = (size_t)v.B * (v.N + 1) * 15 * sizeof(double);
+    const size_t vec = (size_t)v.B * (v.N + 1) * 15 * sizeof(real_t);
     if (b->stage_zero_pending) {
         HIP_TRY(hipMemsetAsync(v.zLow, 0, (size_t)((char*)v.p - (char*)v.zLow), b->stream));
     } else if (b->zy_zero_pending) {
@@ -241,8 +241,8 @@ int materialise_jacobians(nmpc_batch* b) {
     }
     if (!b->jacobians_zero_pending) return 0;
     const BatchView& v = b->v;
-    HIP_TRY(hipMemsetAsync(v.C, 0, (size_t)v.B * v.N * 180 * sizeof(double), b->stream));
-    HIP_TRY(hipMemsetAsync(v.c, 0, (size_t)v.B * v.N * 12 * sizeof(double), b->stream));
+    HIP_TRY(hipMemsetAsync(v.C, 0, (size_t)v.B * v.N * 180 * sizeof(real_t), b->stream));
+    HIP_TRY(hipMemsetAsync(v.c, 0, (size_t)v.B * v.N * 12 * sizeof(real_t), b->stream));
     b->jacobians_zero_pending = false;
     return 0;
 }
@@ -278,7 +278,7 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
     v.head = v.xhead = v.lhead = 0;
 
     struct Field { void** p; size_t bytes; };
-    const size_t d = sizeof(double);
+    const size_t d = sizeof(real_t);
     // The last three fields are rebuilt in full by nmpc_batch_init (C) and by
     // the first solve after it (hess, chol); nmpc_batch_reset skips them.
     Field fields[] = {
@@ -375,7 +375,7 @@ int nmpc_batch_synchronize(nmpc_batch_t* b) {
 #define SETTER(name, field, n)                                          \
     int name(nmpc_batch_t* b, const real_t* coeffs) {                   \
         if (!b || !coeffs) return fail(NMPC_E_ARG, #name ": null argument"); \
-        memcpy(b->field, coeffs, (n) * sizeof(double));                 \
+        memcpy(b->field, coeffs, (n) * sizeof(real_t));                 \
         return 0;                                                       \
     }
 SETTER(nmpc_batch_set_state_weights, wq, 12)
@@ -414,7 +414,7 @@ int nmpc_batch_init(nmpc_batch_t* b) {
 int nmpc_batch_set_wind_velocity(nmpc_batch_t* b, const real_t* wind) {
     if (!b || !wind) return fail(NMPC_E_ARG, "nmpc_batch_set_wind_velocity: null argument");
     TRY(use_device(b));
-    HIP_TRY(hipMemcpyAsync(b->v.wind, wind, (size_t)b->v.B * 3 * sizeof(double),
+    HIP_TRY(hipMemcpyAsync(b->v.wind, wind, (size_t)b->v.B * 3 * sizeof(real_t),
                            hipMemcpyDefault, b->stream));
     if (!is_device_pointer(wind)) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
@@ -422,7 +422,7 @@ int nmpc_batch_set_wind_velocity(nmpc_batch_t* b, const real_t* wind) {
 
 // Reference points already in device memory ([B][count][16]) -> rings, then the
 // linearisation of the stages they complete.
-static int store_and_linearise(nmpc_batch* b, const double* dev, uint32_t first, uint32_t count) {
+static int store_and_linearise(nmpc_batch* b, const real_t* dev, uint32_t first, uint32_t count) {
     sync_config(b);
     if (b->stage_zero_pending) TRY(materialise_stage_vectors(b));
     TRY(timed(b, NMPC_K_OTHER, [&] {
@@ -453,8 +453,8 @@ int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_
     TRY(use_device(b));
     const void* dev = nullptr;
     const bool host = !is_device_pointer(refs);
-    TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(double), &dev));
-    TRY(store_and_linearise(b, (const double*)dev, first, count));
+    TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(real_t), &dev));
+    TRY(store_and_linearise(b, (const real_t*)dev, first, count));
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));   // caller may reuse its buffer
     return 0;
 }
@@ -471,13 +471,13 @@ int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t* b, const real_t* waypo
     const size_t B = (size_t)b->v.B;
     const void* dwp = nullptr;
     const bool host = !is_device_pointer(waypoints);
-    TRY(stage_in(b, b->in_wind, waypoints, B * n_waypoints * 17 * sizeof(double), &dwp));
-    TRY(b->scratch.reserve(B * count * 16 * sizeof(double)));
+    TRY(stage_in(b, b->in_wind, waypoints, B * n_waypoints * 17 * sizeof(real_t), &dwp));
+    TRY(b->scratch.reserve(B * count * 16 * sizeof(real_t)));
     TRY(timed(b, NMPC_K_OTHER, [&] {
-        launch_refs_from_waypoints((int)B, (const double*)dwp, (int)n_waypoints, t0, dt, (int)first,
-                                   (int)count, (double*)b->scratch.ptr, b->stream);
+        launch_refs_from_waypoints((int)B, (const real_t*)dwp, (int)n_waypoints, t0, dt, (int)first,
+                                   (int)count, (real_t*)b->scratch.ptr, b->stream);
     }));
-    TRY(store_and_linearise(b, (const double*)b->scratch.ptr, first, count));
+    TRY(store_and_linearise(b, (const real_t*)b->scratch.ptr, first, count));
     if (host) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -489,13 +489,13 @@ int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t* b, const real_t* waypo
 // of 16 doubles, 8 MiB on every GPU the library runs on, held until the
 // process ends and shared by all batches on that GPU.
 constexpr uint32_t kStaticPoints = NMPC_STATIC_SCRATCH_POINTS;
-static __device__ __align__(256) double scratch[(size_t)kStaticPoints * 16];
+static __device__ __align__(256) real_t scratch[(size_t)kStaticPoints * 16];
 constexpr int kMaxDevices = 64;
-static double* g_scratch_ptr[kMaxDevices];      // device address of `scratch`, per GPU
+static real_t* g_scratch_ptr[kMaxDevices];      // device address of `scratch`, per GPU
 
 // The array's name is only a handle on the host; its memory on the current
 // device is found once per device.
-static int static_scratch(int device, double** out) {
+static int static_scratch(int device, real_t** out) {
     if (device < 0 || device >= kMaxDevices)
         return fail(NMPC_E_ARG, "device %d beyond the %d the library keeps scratch addresses for",
                     device, kMaxDevices);
@@ -503,7 +503,7 @@ static int static_scratch(int device, double** out) {
         void* ptr = nullptr;
         HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
         if (!ptr) return fail(NMPC_E_HIP, "hipGetSymbolAddress returned a null address");
-        g_scratch_ptr[device] = (double*)ptr;
+        g_scratch_ptr[device] = (real_t*)ptr;
     }
     *out = g_scratch_ptr[device];
     return 0;
@@ -527,7 +527,7 @@ int nmpc_batch_set_reference_from_waypoints_noalloc(nmpc_batch_t* b, const real_
     if (!is_device_pointer(waypoints))
         return fail(NMPC_E_ARG, "nmpc_batch_set_reference_from_waypoints_noalloc: waypoints must be "
                     "device memory (a host buffer would need a staging allocation)");
-    double* points_dev = nullptr;
+    real_t* points_dev = nullptr;
     TRY(static_scratch(b->device, &points_dev));
     struct Untimed {        // timing a launch may create events
         nmpc_batch* b;
@@ -536,7 +536,7 @@ int nmpc_batch_set_reference_from_waypoints_noalloc(nmpc_batch_t* b, const real_
     } untimed(b);
     // every entry of the points the kernels below read is written first: nothing
     // of an earlier call's contents is looked at
-    launch_refs_from_waypoints(b->v.B, (const double*)waypoints, (int)n_waypoints, t0, dt, (int)first,
+    launch_refs_from_waypoints(b->v.B, (const real_t*)waypoints, (int)n_waypoints, t0, dt, (int)first,
                                (int)count, points_dev, b->stream);
     HIP_TRY(hipGetLastError());
     return store_and_linearise(b, points_dev, first, count);
@@ -590,8 +590,8 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     b->zy_zero_pending = false;             // the opening step writes every z and y
     const void* dev = nullptr;
     const bool host = !is_device_pointer(measurement);
-    TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(double), &dev));
-    const double* dmeas = (const double*)dev;
+    TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(real_t), &dev));
+    const real_t* dmeas = (const real_t*)dev;
     const BatchView& v = b->v;
     // the launches below follow each other with nothing between them
     struct ChainScope {
@@ -620,15 +620,15 @@ int nmpc_batch_get_controls(nmpc_batch_t* b, real_t* controls, int32_t* status,
     const bool du = controls && is_device_pointer(controls);
     const bool ds = status && is_device_pointer(status);
     const bool di = iterations && is_device_pointer(iterations);
-    if (!du) TRY(b->out_u.reserve(B * 3 * sizeof(double)));
+    if (!du) TRY(b->out_u.reserve(B * 3 * sizeof(real_t)));
     if (!ds) TRY(b->out_status.reserve(B * sizeof(int)));
     if (!di) TRY(b->out_iters.reserve(B * sizeof(int)));
-    double* pu = du ? controls : (double*)b->out_u.ptr;
+    real_t* pu = du ? controls : (real_t*)b->out_u.ptr;
     int* ps = ds ? status : (int*)b->out_status.ptr;
     int* pi = di ? iterations : (int*)b->out_iters.ptr;
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_gather_results(b->v, pu, ps, pi, b->stream); }));
     if (controls && !du)
-        HIP_TRY(hipMemcpyAsync(controls, pu, B * 3 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(controls, pu, B * 3 * sizeof(real_t), hipMemcpyDeviceToHost, b->stream));
     if (status && !ds)
         HIP_TRY(hipMemcpyAsync(status, ps, B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
     if (iterations && !di)
@@ -647,14 +647,14 @@ int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
     BatchView& v = b->v;
     const void* dev = nullptr;
     const bool host = !is_device_pointer(new_reference);
-    TRY(stage_in(b, b->in_refs, new_reference, (size_t)v.B * 16 * sizeof(double), &dev));
+    TRY(stage_in(b, b->in_refs, new_reference, (size_t)v.B * 16 * sizeof(real_t), &dev));
     // shift references, multipliers and stage records by one position
     v.xhead = (v.xhead + 1) % (v.N + 1);
     v.lhead = (v.lhead + 1) % v.N;
     v.head = (v.head + 1) % v.N;
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_shift_lambda_tail(v, b->stream); }));
     TRY(timed(b, NMPC_K_OTHER, [&] {
-        launch_store_refs(v, (const double*)dev, v.N, 1, b->stream);
+        launch_store_refs(v, (const real_t*)dev, v.N, 1, b->stream);
     }));
     TRY(timed(b, NMPC_K_LINEARISE, [&] { launch_linearise(v, v.N - 1, 1, b->stream); }));
     b->fresh.erase(b->fresh.begin());       // the stage records moved up by one position
@@ -666,7 +666,7 @@ int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
 // ---- plant roll-forward --------------------------------------------------------
 static int plant_buffer(nmpc_batch* b) {
     if (b->plant) return 0;
-    const size_t bytes = (size_t)b->v.B * 13 * sizeof(double);
+    const size_t bytes = (size_t)b->v.B * 13 * sizeof(real_t);
     HIP_TRY(hipMalloc((void**)&b->plant, bytes));
     HIP_TRY(hipMalloc((void**)&b->plant_next, bytes));
     HIP_TRY(hipMemsetAsync(b->plant, 0, bytes, b->stream));
@@ -677,7 +677,7 @@ int nmpc_batch_plant_set_state(nmpc_batch_t* b, const real_t* state) {
     if (!b || !state) return fail(NMPC_E_ARG, "nmpc_batch_plant_set_state: null argument");
     TRY(use_device(b));
     TRY(plant_buffer(b));
-    HIP_TRY(hipMemcpyAsync(b->plant, state, (size_t)b->v.B * 13 * sizeof(double), hipMemcpyDefault,
+    HIP_TRY(hipMemcpyAsync(b->plant, state, (size_t)b->v.B * 13 * sizeof(real_t), hipMemcpyDefault,
                            b->stream));
     if (!is_device_pointer(state)) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
@@ -687,7 +687,7 @@ int nmpc_batch_plant_get_state(nmpc_batch_t* b, real_t* state) {
     if (!b || !state) return fail(NMPC_E_ARG, "nmpc_batch_plant_get_state: null argument");
     TRY(use_device(b));
     TRY(plant_buffer(b));
-    HIP_TRY(hipMemcpyAsync(state, b->plant, (size_t)b->v.B * 13 * sizeof(double), hipMemcpyDefault,
+    HIP_TRY(hipMemcpyAsync(state, b->plant, (size_t)b->v.B * 13 * sizeof(real_t), hipMemcpyDefault,
                            b->stream));
     if (!is_device_pointer(state)) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
@@ -704,24 +704,24 @@ int nmpc_batch_plant_integrate(nmpc_batch_t* b, real_t dt, const real_t* control
     bool host = false;
     if (controls) {
         host = host || !is_device_pointer(controls);
-        TRY(stage_in(b, b->in_meas, controls, B * 3 * sizeof(double), &du));
+        TRY(stage_in(b, b->in_meas, controls, B * 3 * sizeof(real_t), &du));
     } else {
         // the controls every instance would report now
-        TRY(b->out_u.reserve(B * 3 * sizeof(double)));
+        TRY(b->out_u.reserve(B * 3 * sizeof(real_t)));
         TRY(b->out_status.reserve(B * sizeof(int)));
         TRY(b->out_iters.reserve(B * sizeof(int)));
         TRY(timed(b, NMPC_K_OTHER, [&] {
-            launch_gather_results(b->v, (double*)b->out_u.ptr, (int*)b->out_status.ptr,
+            launch_gather_results(b->v, (real_t*)b->out_u.ptr, (int*)b->out_status.ptr,
                                   (int*)b->out_iters.ptr, b->stream);
         }));
         du = b->out_u.ptr;
     }
     if (wind) {
         host = host || !is_device_pointer(wind);
-        TRY(stage_in(b, b->in_wind, wind, B * 3 * sizeof(double), &dw));
+        TRY(stage_in(b, b->in_wind, wind, B * 3 * sizeof(real_t), &dw));
     }
     TRY(timed(b, NMPC_K_OTHER, [&] {
-        launch_rk4_free((long)B, b->plant, (const double*)du, (const double*)dw, dt, b->plant_next,
+        launch_rk4_free((long)B, b->plant, (const real_t*)du, (const real_t*)dw, dt, b->plant_next,
                         b->stream);
     }));
     std::swap(b->plant, b->plant_next);
@@ -755,8 +755,8 @@ int nmpc_batch_get_stage(nmpc_batch_t* b, uint32_t instance, uint32_t k, real_t*
     const size_t N = v.N, N1 = N + 1, ib = instance;
     const size_t s = k < N ? (size_t)((v.head + k) % v.N) : N;
     const size_t nv = k < N ? 15 : 12;
-    memset(o, 0, 332 * sizeof(double));
-    const size_t d = sizeof(double);
+    memset(o, 0, 332 * sizeof(real_t));
+    const size_t d = sizeof(real_t);
     if (k < N) {
         TRY(d2h(b, o, v.C + (ib * N + s) * 180, 180 * d));
         TRY(d2h(b, o + 180, v.c + (ib * N + s) * 12, 12 * d));
@@ -787,7 +787,7 @@ int nmpc_batch_get_global(nmpc_batch_t* b, uint32_t instance, real_t* o) {
     const BatchView& v = b->v;
     if (instance >= (uint32_t)v.B) return fail(NMPC_E_ARG, "instance out of range");
     TRY(use_device(b));
-    const size_t N = v.N, N1 = N + 1, ib = instance, d = sizeof(double);
+    const size_t N = v.N, N1 = N + 1, ib = instance, d = sizeof(real_t);
     // lambda, position order
     for (size_t k = 0; k < N; k++) {
         const size_t ls = (size_t)((v.lhead + (int)k) % v.N);
@@ -801,8 +801,8 @@ int nmpc_batch_get_global(nmpc_batch_t* b, uint32_t instance, real_t* o) {
     std::vector<int8_t> ie(N1 * 15), pr(N1 * 15);
     TRY(d2h(b, ie.data(), v.ieq + ib * N1 * 15, N1 * 15));
     TRY(d2h(b, pr.data(), v.prev + ib * N1 * 15, N1 * 15));
-    double* oi = o; o += 15 * N1;
-    double* op = o; o += 15 * N1;
+    real_t* oi = o; o += 15 * N1;
+    real_t* op = o; o += 15 * N1;
     for (size_t k = 0; k < N1; k++) {
         const size_t xs = (size_t)((v.xhead + (int)k) % (v.N + 1));
         TRY(d2h(b, o + 13 * k, v.xref + (ib * N1 + xs) * 13, 13 * d));
@@ -819,8 +819,8 @@ int nmpc_batch_get_global(nmpc_batch_t* b, uint32_t instance, real_t* o) {
     for (size_t k = 0; k < N1; k++)
         for (size_t i = 0; i < 15; i++) {
             const bool valid = i < (k < N ? 15u : 12u);
-            oi[k * 15 + i] = valid ? (double)ie[k * 15 + i] : 0.0;
-            op[k * 15 + i] = valid ? (double)pr[k * 15 + i] : 0.0;
+            oi[k * 15 + i] = valid ? (real_t)ie[k * 15 + i] : 0.0;
+            op[k * 15 + i] = valid ? (real_t)pr[k * 15 + i] : 0.0;
         }
     o[0] = sc.u[0]; o[1] = sc.u[1]; o[2] = sc.u[2];
     return 0;
@@ -905,16 +905,16 @@ int nmpc_linearise_samples(int device, void* stream, uint64_t n, const real_t* x
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    const size_t d = sizeof(double);
+    const size_t d = sizeof(real_t);
     TempCopy tx, tu, tn, tw, tj, tr;
     TRY(temp_in(tx, x, n * 13 * d, s)); TRY(temp_in(tu, u, n * 3 * d, s));
     TRY(temp_in(tn, x_next, n * 13 * d, s)); TRY(temp_in(tw, wind, n * 3 * d, s));
     TRY(temp_out(tj, jacobian, n * 180 * d)); TRY(temp_out(tr, residual, n * 12 * d));
     Bounds bnd;
     memcpy(bnd.lb, lower, sizeof bnd.lb); memcpy(bnd.ub, upper, sizeof bnd.ub);
-    launch_linearise_free((long)n, (const double*)tx.dev, (const double*)tu.dev,
-                          (const double*)tn.dev, (const double*)tw.dev, bnd, (double*)tj.dev,
-                          (double*)tr.dev, s);
+    launch_linearise_free((long)n, (const real_t*)tx.dev, (const real_t*)tu.dev,
+                          (const real_t*)tn.dev, (const real_t*)tw.dev, bnd, (real_t*)tj.dev,
+                          (real_t*)tr.dev, s);
     HIP_TRY(hipGetLastError());
     TRY(finish_out(tj, jacobian, n * 180 * d, s));
     TRY(finish_out(tr, residual, n * 12 * d, s));
@@ -929,12 +929,12 @@ int nmpc_rk4_samples(int device, void* stream, uint64_t n, const real_t* x, cons
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    const size_t d = sizeof(double);
+    const size_t d = sizeof(real_t);
     TempCopy tx, tu, tw, to;
     TRY(temp_in(tx, x, n * 13 * d, s)); TRY(temp_in(tu, u, n * 3 * d, s));
     TRY(temp_in(tw, wind, n * 3 * d, s)); TRY(temp_out(to, out, n * 13 * d));
-    launch_rk4_free((long)n, (const double*)tx.dev, (const double*)tu.dev, (const double*)tw.dev,
-                    delta, (double*)to.dev, s);
+    launch_rk4_free((long)n, (const real_t*)tx.dev, (const real_t*)tu.dev, (const real_t*)tw.dev,
+                    delta, (real_t*)to.dev, s);
     HIP_TRY(hipGetLastError());
     TRY(finish_out(to, out, n * 13 * d, s));
     if (tx.owned || tu.owned || tw.owned || to.owned) HIP_TRY(hipStreamSynchronize(s));
@@ -948,9 +948,9 @@ namespace {
 
 struct Single {
     nmpc_batch* batch = nullptr;
-    double wq[12] = {0}, wr[3] = {0}, wt[12] = {0}, lb[3] = {0}, ub[3] = {0};
-    double wind[3] = {0};
-    double plant[13] = {0};     // c/cnmpc.cpp:33 `current`
+    real_t wq[12] = {0}, wr[3] = {0}, wt[12] = {0}, lb[3] = {0}, ub[3] = {0};
+    real_t wind[3] = {0};
+    real_t plant[13] = {0};     // c/cnmpc.cpp:33 `current`
 };
 Single g_single;
 
@@ -1042,9 +1042,9 @@ void nmpc_fixedwingdynamics_get_state(struct nmpc_state_t* in) { memcpy(in, g_si
 
 void nmpc_fixedwingdynamics_integrate(float dt, real_t control_vector[NMPC_CONTROL_DIM]) {
     nmpc_batch* b = single();
-    double next[13];
+    real_t next[13];
     MUST(nmpc_rk4_samples(b->device, nullptr, 1, g_single.plant, control_vector, g_single.wind,
-                          (double)dt, next));
+                          (real_t)dt, next));
     memcpy(g_single.plant, next, sizeof next);
 }
 
@@ -1052,6 +1052,8 @@ uint32_t nmpc_config_get_state_dim(void) { return NMPC_STATE_DIM; }
 uint32_t nmpc_config_get_control_dim(void) { return NMPC_CONTROL_DIM; }
 uint32_t nmpc_config_get_horizon_length(void) { return OCP_HORIZON_LENGTH; }
 real_t nmpc_config_get_step_length(void) { return OCP_STEP_LENGTH; }
-enum nmpc_precision_t nmpc_config_get_precision(void) { return NMPC_PRECISION_DOUBLE; }
+enum nmpc_precision_t nmpc_config_get_precision(void) {
+    return sizeof(real_t) == 8 ? NMPC_PRECISION_DOUBLE : NMPC_PRECISION_FLOAT;
+}
 
 }  // extern "C"

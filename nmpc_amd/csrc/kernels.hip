@@ -45,31 +45,31 @@ namespace nmpc {
 // re-normalised (scaled by 1 / |q|, scripts/vectors.py:299-310).  Past the last
 // waypoint the last waypoint is returned as it is; before the first one the
 // first (the harness never asks for that).
-__global__ void k_refs_from_waypoints(int B, const double* __restrict__ wp, int W, double t0,
-                                      double dt, int first, int count, double* __restrict__ out) {
+__global__ void k_refs_from_waypoints(int B, const real_t* __restrict__ wp, int W, real_t t0,
+                                      real_t dt, int first, int count, real_t* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * count) return;
     const int b = t / count, i = t % count;
-    const double* P = wp + (size_t)b * W * 17;
-    const double at = t0 + (double)(first + i) * dt;
+    const real_t* P = wp + (size_t)b * W * 17;
+    const real_t at = t0 + (real_t)(first + i) * dt;
     int index = 0;                              // bisect.bisect: first waypoint later than `at`
     while (index < W && !(at < P[index * 17])) ++index;
-    double* o = out + (size_t)t * 16;
+    real_t* o = out + (size_t)t * 16;
     if (index >= W || index == 0) {
-        const double* src = P + (index >= W ? W - 1 : 0) * 17;
+        const real_t* src = P + (index >= W ? W - 1 : 0) * 17;
         for (int j = 0; j < 16; j++) o[j] = src[1 + j];
         return;
     }
-    const double* a = P + (index - 1) * 17;
-    const double* c = P + index * 17;
-    const double r = (at - a[0]) / (c[0] - a[0]);
-    double pt[16];
+    const real_t* a = P + (index - 1) * 17;
+    const real_t* c = P + index * 17;
+    const real_t r = (at - a[0]) / (c[0] - a[0]);
+    real_t pt[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) pt[j] = a[1 + j] + (c[1 + j] - a[1 + j]) * r;
-    double m = 0.;
+    real_t m = 0.;
 #pragma unroll
     for (int j = 6; j < 10; j++) m += pt[j] * pt[j];
-    const double scale = 1.0 / sqrt(m);
+    const real_t scale = 1.0 / sqrt(m);
 #pragma unroll
     for (int j = 6; j < 10; j++) pt[j] = pt[j] * scale;
 #pragma unroll
@@ -79,18 +79,18 @@ __global__ void k_refs_from_waypoints(int B, const double* __restrict__ wp, int 
 // ------------------------------------------------------------------------
 // refs: [B][count][16] staging buffer; point i of the range goes to horizon
 // position first + i.  Control part of position p >= 1 belongs to stage p - 1.
-__global__ void k_store_refs(BatchView v, const double* __restrict__ refs,
+__global__ void k_store_refs(BatchView v, const real_t* __restrict__ refs,
                              int first, int count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = v.B * count;
     if (t >= total) return;
     const int b = t / count, i = t % count, pos = first + i;
-    const double* r = refs + (size_t)t * 16;
-    double* x = v.xref + ((size_t)b * (v.N + 1) + xref_slot(v, pos)) * NS;
+    const real_t* r = refs + (size_t)t * 16;
+    real_t* x = v.xref + ((size_t)b * (v.N + 1) + xref_slot(v, pos)) * NS;
 #pragma unroll
     for (int e = 0; e < NS; e++) x[e] = r[e];
     if (pos >= 1) {
-        double* u = v.uref + ((size_t)b * v.N + stage_slot(v, pos - 1)) * NU;
+        real_t* u = v.uref + ((size_t)b * v.N + stage_slot(v, pos - 1)) * NU;
         u[0] = r[13]; u[1] = r[14]; u[2] = r[15];
     }
 }
@@ -119,26 +119,26 @@ __global__ void k_init_stages(BatchView v, int part) {
     const int nV = k < v.N ? NZ : NX;
     if (i >= nV) return;
     const int s = stage_slot(v, k);
-    const double* H = stage_hessian(v, k);
-    double qs = 0., ps = 0.;
+    const real_t* H = stage_hessian(v, k);
+    real_t qs = 0., ps = 0.;
     if (k < v.N) {
-        const double* l1 = I.lam + (size_t)lam_slot(v, k) * NX;
+        const real_t* l1 = I.lam + (size_t)lam_slot(v, k) * NX;
         for (int m = 0; m < NX; m++) {
-            const double li = l1[m];
+            const real_t li = l1[m];
             qs += 0.0 * li;
             ps += li * 0.0;
         }
     }
     if (k > 0 && i < NX) qs -= I.lam[(size_t)lam_slot(v, k - 1) * NX + i];
     if (i == 0) I.pStep[s] = ps;
-    const double qv = qs + 0.0;
+    const real_t qv = qs + 0.0;
     const int e = s * NZ + i;
     I.qStep[e] = qv;
-    const double d = qv / H[i];
+    const real_t d = qv / H[i];
     I.dz[e] = -d;
     I.zUnc[e] = 0.0;
     I.q[e] = 0.0;
-    double lo = -kInfty, up = kInfty;
+    real_t lo = -kInfty, up = kInfty;
     if (i >= NX) { lo = v.lb[i - NX]; up = v.ub[i - NX]; }
     I.zLow[e] = lo;
     I.zUpp[e] = up;
@@ -158,11 +158,11 @@ __global__ void k_init_stages(BatchView v, int part) {
 // broadcasts, and the next state is only unpacked once the integration is over.
 using Seq12 = std::make_integer_sequence<int, NX>;
 template <int... I>
-NMPC_DEV void gather_row(double (&out)[NS], double mine, std::integer_sequence<int, I...>) {
+NMPC_DEV void gather_row(real_t (&out)[NS], real_t mine, std::integer_sequence<int, I...>) {
     ((out[I] = row_bcast<I>(mine)), ...);
 }
 template <int... I>
-NMPC_DEV void bcast_from_last(double (&out)[NS], const double (&in)[NS],
+NMPC_DEV void bcast_from_last(real_t (&out)[NS], const real_t (&in)[NS],
                               std::integer_sequence<int, I...>) {
     ((out[I] = row_bcast<15>(in[I])), ...);
 }
@@ -170,24 +170,24 @@ NMPC_DEV void bcast_from_last(double (&out)[NS], const double (&in)[NS],
 // zdev: null, or the stage variable z (15 entries) the expansion point is moved
 // by: x (+) z[0:12], u + z[12:15]; this lane's entry of it comes back in *zj.
 template <int... I>
-NMPC_DEV void gather_row15(double (&out)[NZ], double mine, std::integer_sequence<int, I...>) {
+NMPC_DEV void gather_row15(real_t (&out)[NZ], real_t mine, std::integer_sequence<int, I...>) {
     ((out[I] = row_bcast<I>(mine)), ...);
 }
 
-NMPC_DEV void linearise_lane(const double* xr, const double* xq, const double* ur,
-                             const double* wr, const double* lower, const double* upper,
-                             int j, double* out12, const double* zdev = nullptr,
-                             double* zj = nullptr) {
+NMPC_DEV void linearise_lane(const real_t* xr, const real_t* xq, const real_t* ur,
+                             const real_t* wr, const real_t* lower, const real_t* upper,
+                             int j, real_t* out12, const real_t* zdev = nullptr,
+                             real_t* zj = nullptr) {
     using Seq13 = std::make_integer_sequence<int, NS>;
     const int li = j < NS ? j : 0;
-    const double mine = xr[li], mine_next = xq[li];
-    double x[NS], u[NU], wind[3], moved[NS], base[NS], next[NS];
+    const real_t mine = xr[li], mine_next = xq[li];
+    real_t x[NS], u[NU], wind[3], moved[NS], base[NS], next[NS];
     gather_row(x, mine, Seq13{});
 #pragma unroll
     for (int i = 0; i < NU; i++) { u[i] = ur[i]; wind[i] = wr[i]; }
     if (zdev) {
-        const double zmine = zdev[j < NZ ? j : 0];
-        double z[NZ], x0[NS];
+        const real_t zmine = zdev[j < NZ ? j : 0];
+        real_t z[NZ], x0[NS];
         gather_row15(z, zmine, std::make_integer_sequence<int, NZ>{});
 #pragma unroll
         for (int i = 0; i < NS; i++) x0[i] = x[i];
@@ -196,7 +196,7 @@ NMPC_DEV void linearise_lane(const double* xr, const double* xq, const double* u
         for (int i = 0; i < NU; i++) u[i] = u[i] + z[NX + i];
         *zj = zmine;
     }
-    const double hinv = perturb_point(x, u, j, lower, upper);
+    const real_t hinv = perturb_point(x, u, j, lower, upper);
     rk4_step(moved, x, u, wind, kStepLength);
     bcast_from_last(base, moved, Seq13{});              // nominal end state
     gather_row(next, mine_next, Seq13{});               // (every lane of the row takes part)
@@ -210,8 +210,8 @@ NMPC_DEV void linearise_lane(const double* xr, const double* xq, const double* u
 }
 
 template <int... I>
-NMPC_DEV double dot_with_row(const double (&col)[NX], double mine, std::integer_sequence<int, I...>) {
-    double acc = 0.;
+NMPC_DEV real_t dot_with_row(const real_t (&col)[NX], real_t mine, std::integer_sequence<int, I...>) {
+    real_t acc = 0.;
     ((acc += col[I] * row_bcast<I>(mine)), ...);
     return acc;
 }
@@ -225,8 +225,8 @@ NMPC_DEV double dot_with_row(const double (&col)[NX], double mine, std::integer_
 // stays a deviation from the reference: c = delta(x_ref[k+1], f(x, u)) - C z
 // (the real-time-iteration preparation step; the reference has no code for it).
 template <int... J>
-NMPC_DEV double sum_over_columns(double mine, std::integer_sequence<int, J...>) {
-    double acc = 0.;
+NMPC_DEV real_t sum_over_columns(real_t mine, std::integer_sequence<int, J...>) {
+    real_t acc = 0.;
     ((acc += row_bcast<J>(mine)), ...);
     return acc;
 }
@@ -241,18 +241,18 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
     if (!live) st = total - 1;              // keep the whole group in the broadcasts
     const int b = (int)(st / count), k = first + (int)(st % count);
     const int s = stage_slot(v, k);
-    const double* ur = v.uref + ((size_t)b * v.N + s) * NU;
+    const real_t* ur = v.uref + ((size_t)b * v.N + s) * NU;
     // multipliers of the two coupling constraints this stage takes part in
-    const double* lam = v.lam + (size_t)b * v.N * NX;
-    const double lam_next = lam[(size_t)lam_slot(v, k) * NX + (j < NX ? j : 0)];
+    const real_t* lam = v.lam + (size_t)b * v.N * NX;
+    const real_t lam_next = lam[(size_t)lam_slot(v, k) * NX + (j < NX ? j : 0)];
     const bool has_prev = k > 0 && j < NX;
-    const double lam_prev = has_prev ? lam[(size_t)lam_slot(v, k - 1) * NX + j] : 0.;
-    double hj = v.H[0], lo = -kInfty, up = kInfty;
+    const real_t lam_prev = has_prev ? lam[(size_t)lam_slot(v, k - 1) * NX + j] : 0.;
+    real_t hj = v.H[0], lo = -kInfty, up = kInfty;
 #pragma unroll
     for (int i = 1; i < NZ; i++) hj = (i == j) ? v.H[i] : hj;
     if (j >= NX && j < NZ) {
-        const double uj = ur[j - NX];
-        double lbj = 0.0, ubj = 0.0;
+        const real_t uj = ur[j - NX];
+        real_t lbj = 0.0, ubj = 0.0;
 #pragma unroll
         for (int i = 0; i < NU; i++) {
             lbj = (i == j - NX) ? v.lb[i] : lbj;
@@ -261,36 +261,36 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
         lo = lbj - uj;
         up = ubj - uj;
     }
-    double col[NX];
+    real_t col[NX];
     {
-        const double* xref = v.xref + (size_t)b * (v.N + 1) * NS;
-        double zj = 0.;
-        const double* zdev = ABOUT_SOLUTION ? v.z + ((size_t)b * (v.N + 1) + s) * NZ : nullptr;
+        const real_t* xref = v.xref + (size_t)b * (v.N + 1) * NS;
+        real_t zj = 0.;
+        const real_t* zdev = ABOUT_SOLUTION ? v.z + ((size_t)b * (v.N + 1) + s) * NZ : nullptr;
         linearise_lane(xref + (size_t)xref_slot(v, k) * NS, xref + (size_t)xref_slot(v, k + 1) * NS,
                        ur, v.wind + (size_t)b * 3, v.lb, v.ub, j, col, zdev, &zj);
         if (ABOUT_SOLUTION) {
             // row r of C z: the columns' products added in column order; lane 15 keeps them
 #pragma unroll
             for (int r = 0; r < NX; r++) {
-                const double prod = (j < NZ) ? col[r] * zj : 0.;
-                const double cz = sum_over_columns(prod, std::make_integer_sequence<int, NZ>{});
+                const real_t prod = (j < NZ) ? col[r] * zj : 0.;
+                const real_t cz = sum_over_columns(prod, std::make_integer_sequence<int, NZ>{});
                 if (j == 15) col[r] = col[r] - cz;
             }
         }
     }
     // C' lambda_{k+1} (lanes j < 15) and c . lambda_{k+1} (lane 15): the same sum
-    const double dot = dot_with_row(col, lam_next, Seq12{});
+    const real_t dot = dot_with_row(col, lam_next, Seq12{});
     if (!live) return;
 
     const size_t sb = (size_t)b, N = (size_t)v.N, N1 = N + 1;
     if (j < 15) {
-        double* Ck = v.C + (sb * N + s) * (NX * NZ);
+        real_t* Ck = v.C + (sb * N + s) * (NX * NZ);
 #pragma unroll
         for (int r = 0; r < NX; r++) Ck[r * NZ + j] = col[r];
-        double qs = dot;
+        real_t qs = dot;
         if (has_prev) qs -= lam_prev;
         qs = qs + 0.0;
-        const double d = qs / hj;
+        const real_t d = qs / hj;
         const size_t e = (sb * N1 + s) * NZ + j;
         v.qStep[e] = qs;
         v.dz[e] = -d;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
         v.zLow[e] = lo;
         v.zUpp[e] = up;
     } else {
-        double* cs = v.c + (sb * N + s) * NX;
+        real_t* cs = v.c + (sb * N + s) * NX;
 #pragma unroll
         for (int i = 0; i < NX; i++) cs[i] = col[i];
         v.pStep[sb * N1 + s] = dot;
@@ -309,15 +309,15 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
 // Stateless variant: n samples, inputs [n][13] [n][3] [n][13] [n][3],
 // outputs jac [n][180] (row-major 12x15) and res [n][12].
 __global__ __launch_bounds__(256, NMPC_LINEARISE_FREE_WAVES) void k_linearise_free(
-    long n, const double* __restrict__ xs, const double* __restrict__ us,
-    const double* __restrict__ xnexts, const double* __restrict__ winds,
-    Bounds bnd, double* __restrict__ jac, double* __restrict__ res) {
+    long n, const real_t* __restrict__ xs, const real_t* __restrict__ us,
+    const real_t* __restrict__ xnexts, const real_t* __restrict__ winds,
+    Bounds bnd, real_t* __restrict__ jac, real_t* __restrict__ res) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int j = (int)(gid & 15);
     long st = gid >> 4;
     const bool live = st < n;
     if (!live) st = n - 1;
-    double col[NX];
+    real_t col[NX];
     linearise_lane(xs + st * NS, xnexts + st * NS, us + st * NU, winds + st * 3, bnd.lb, bnd.ub, j, col);
     if (!live) return;
     if (j < 15) {
@@ -329,13 +329,13 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_FREE_WAVES) void k_linearise_fr
     }
 }
 
-__global__ __launch_bounds__(256) void k_rk4_free(long n, const double* __restrict__ xs,
-                           const double* __restrict__ us,
-                           const double* __restrict__ winds, double delta,
-                           double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_rk4_free(long n, const real_t* __restrict__ xs,
+                           const real_t* __restrict__ us,
+                           const real_t* __restrict__ winds, real_t delta,
+                           real_t* __restrict__ out) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    double x[NS], u[NU], w[3], r[NS];
+    real_t x[NS], u[NU], w[3], r[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) x[i] = xs[t * NS + i];
 #pragma unroll
@@ -372,12 +372,12 @@ __global__ void k_shift_lambda_tail(BatchView v) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= v.B * NX) return;
     const int b = t / NX, i = t % NX;
-    double* lam = v.lam + (size_t)b * v.N * NX;
+    real_t* lam = v.lam + (size_t)b * v.N * NX;
     lam[(size_t)lam_slot(v, v.N - 1) * NX + i] = lam[(size_t)lam_slot(v, v.N - 2) * NX + i];
 }
 
 // controls / status / iterations gather: out_u [B][3], out_status [B], out_iters [B]
-__global__ void k_gather_results(BatchView v, double* __restrict__ out_u,
+__global__ void k_gather_results(BatchView v, real_t* __restrict__ out_u,
                                  int* __restrict__ out_status, int* __restrict__ out_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= v.B) return;
@@ -394,12 +394,12 @@ __global__ void k_gather_results(BatchView v, double* __restrict__ out_u,
 // ========================================================================
 static inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-void launch_store_refs(const BatchView& v, const double* refs, int first, int count, hipStream_t s) {
+void launch_store_refs(const BatchView& v, const real_t* refs, int first, int count, hipStream_t s) {
     const long n = (long)v.B * count;
     hipLaunchKernelGGL(k_store_refs, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, refs, first, count);
 }
-void launch_refs_from_waypoints(int B, const double* wp, int W, double t0, double dt, int first,
-                                int count, double* out, hipStream_t s) {
+void launch_refs_from_waypoints(int B, const real_t* wp, int W, real_t t0, real_t dt, int first,
+                                int count, real_t* out, hipStream_t s) {
     const long n = (long)B * count;
     hipLaunchKernelGGL(k_refs_from_waypoints, dim3(blocks_for(n, 256)), dim3(256), 0, s, B, wp, W, t0,
                        dt, first, count, out);
@@ -415,14 +415,14 @@ void launch_linearise(const BatchView& v, int first, int count, hipStream_t s, b
     else
         hipLaunchKernelGGL(k_linearise<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, first, count);
 }
-void launch_linearise_free(long n, const double* x, const double* u, const double* xn,
-                           const double* w, const Bounds& bnd, double* jac, double* res,
+void launch_linearise_free(long n, const real_t* x, const real_t* u, const real_t* xn,
+                           const real_t* w, const Bounds& bnd, real_t* jac, real_t* res,
                            hipStream_t s) {
     hipLaunchKernelGGL(k_linearise_free, dim3(blocks_for(n * 16, 256)), dim3(256), 0, s, n, x, u, xn,
                        w, bnd, jac, res);
 }
-void launch_rk4_free(long n, const double* x, const double* u, const double* w, double delta,
-                     double* out, hipStream_t s) {
+void launch_rk4_free(long n, const real_t* x, const real_t* u, const real_t* w, real_t delta,
+                     real_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_rk4_free, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, x, u, w, delta, out);
 }
 void launch_qp_finish(const BatchView& v, hipStream_t s) {
@@ -431,7 +431,7 @@ void launch_qp_finish(const BatchView& v, hipStream_t s) {
 void launch_shift_lambda_tail(const BatchView& v, hipStream_t s) {
     hipLaunchKernelGGL(k_shift_lambda_tail, dim3(blocks_for((long)v.B * NX, 256)), dim3(256), 0, s, v);
 }
-void launch_gather_results(const BatchView& v, double* u, int* status, int* iters, hipStream_t s) {
+void launch_gather_results(const BatchView& v, real_t* u, int* status, int* iters, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_results, dim3(blocks_for(v.B, 256)), dim3(256), 0, s, v, u, status, iters);
 }
 

@@ -21,6 +21,15 @@
 #pragma once
 #include <stdint.h>
 
+// Arithmetic type of the whole library: double, or float when built with
+// -DNMPC_SINGLE_PRECISION (the reference's shipped configuration,
+// include/config.h:27-28).  Same typedef as include/cnmpc.h.
+#ifdef NMPC_SINGLE_PRECISION
+typedef float real_t;
+#else
+typedef double real_t;
+#endif
+
 namespace nmpc {
 
 // Solver status codes: numeric values of qpDUNES' return_t
@@ -38,9 +47,9 @@ enum : int {
 };
 
 struct Scalars {        // one per instance
-    double objInc;      // incumbent dual objective
-    double alpha;       // last step length
-    double u[3];        // last good controls
+    real_t objInc;      // incumbent dual objective
+    real_t alpha;       // last step length
+    real_t u[3];        // last good controls
     int status;         // ST_*
     int numIter;        // qpData.log.numIter
     int last;           // lastActSetChangeIdx
@@ -48,8 +57,8 @@ struct Scalars {        // one per instance
     int lsIter;         // line-search trial count of the last iteration
     int lastResult;     // 1 = nmpc_get_controls would return NMPC_OK
     // step-length search handed from k_newton_step to k_line_search_tail
-    double dlNorm2;     // squared norm of the Newton step, written by k_newton_solve
-    double lsMin, lsMax, lsMid, lsNormal;
+    real_t dlNorm2;     // squared norm of the Newton step, written by k_newton_solve
+    real_t lsMin, lsMax, lsMid, lsNormal;
     int lsPhase;
     int lsDeferred;
 };
@@ -58,36 +67,36 @@ struct BatchView {
     int B, N;
     int b0, nb;         // instance range [b0, b0 + nb) the QP kernels of one launch cover
     int head, xhead, lhead;
-    double* xref;       // [B][N+1][13]
-    double* uref;       // [B][N][3]      stage slot
-    double* wind;       // [B][3]
-    double* C;          // [B][N][12*15]  stage slot, row-major 12x15
-    double* c;          // [B][N][12]
-    double* zLow;       // [B][N+1][15]
-    double* zUpp;
-    double* q;
-    double* z;
-    double* qStep;
-    double* zUnc;
-    double* dz;
-    double* tmp;        // trial primal vector of the line search; between solves' kernels scratch of k_newton_solve
-    double* y;          // [B][N+1][30]   (lb - z, z - ub) pairs
-    double* p;          // [B][N+1]
-    double* pStep;      // [B][N+1]
-    double* lam;        // [B][N][12]     lambda ring
-    double* dl;         // [B][N][12]
-    double* grad;       // [B][N][12]
-    double* hess;       // [B][N][12][24] "[L D]" block rows (types.h:265-283)
-    double* chol;       // [B][N][12][24]
+    real_t* xref;       // [B][N+1][13]
+    real_t* uref;       // [B][N][3]      stage slot
+    real_t* wind;       // [B][3]
+    real_t* C;          // [B][N][12*15]  stage slot, row-major 12x15
+    real_t* c;          // [B][N][12]
+    real_t* zLow;       // [B][N+1][15]
+    real_t* zUpp;
+    real_t* q;
+    real_t* z;
+    real_t* qStep;
+    real_t* zUnc;
+    real_t* dz;
+    real_t* tmp;        // trial primal vector of the line search; between solves' kernels scratch of k_newton_solve
+    real_t* y;          // [B][N+1][30]   (lb - z, z - ub) pairs
+    real_t* p;          // [B][N+1]
+    real_t* pStep;      // [B][N+1]
+    real_t* lam;        // [B][N][12]     lambda ring
+    real_t* dl;         // [B][N][12]
+    real_t* grad;       // [B][N][12]
+    real_t* hess;       // [B][N][12][24] "[L D]" block rows (types.h:265-283)
+    real_t* chol;       // [B][N][12][24]
     int8_t* ieq;        // [B][N+1][15]
     int8_t* prev;       // [B][N+1][15]
     int8_t* chg;        // [B][N+1]       actSetHasChanged
     Scalars* sc;        // [B]
     int* tailCount;     // [8]  instances handed to k_line_search_tail, per Newton iteration
     int* tailList;      // [B]  their indices
-    double H[15];       // regular-stage Hessian diagonal as the solver sees it
-    double Ht[12];      // terminal-stage Hessian diagonal
-    double lb[3], ub[3];
+    real_t H[15];       // regular-stage Hessian diagonal as the solver sees it
+    real_t Ht[12];      // terminal-stage Hessian diagonal
+    real_t lb[3], ub[3];
 };
 
 }  // namespace nmpc

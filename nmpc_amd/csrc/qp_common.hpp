@@ -15,21 +15,26 @@ namespace nmpc {
 
 // Effective options: qpDUNES defaults (setup_qp.c:667-725) with the overrides
 // of ccs-c66x/cnmpc.c:891-894.
-constexpr double kInfty = 1.e12;
-constexpr double kEqTol = 2.221e-16;
-constexpr double kActTol = 1e4 * 2.221e-16;
-constexpr double kDiagRegTol = 1.e-10;
-constexpr double kRegParam = 1.e-6;
-constexpr double kStatTol = (double)1e-3f;
+// The option fields are real_t (qpDUNES/types.h:487-543): every value is rounded
+// to real_t where it is stored, and the plain double literals next to them in
+// the solver's expressions make those expressions double in both precisions.
+constexpr real_t kInfty = (real_t)1.e12;
+constexpr real_t kEqTol = (real_t)2.221e-16;
+constexpr real_t kActTol = (real_t)(1e4 * kEqTol);
+constexpr real_t kDiagRegTol = (real_t)1.e-10;
+constexpr real_t kRegParam = (real_t)1.e-6;
+constexpr real_t kStatTol = (real_t)1e-3f;
 constexpr int kMaxIter = 5;
 constexpr int kMaxLsIter = 19;
 constexpr int kMaxLsRefine = 40;
-constexpr double kLsReduction = 0.1;
-constexpr double kLsIncrease = 1.5;
-constexpr double kLsMinAbs = 2.221e-16;
-constexpr double kLsMinRel = 1.e-14;
-constexpr double kLsStatTol = 1.e-3;
-constexpr double kLsMaxStep = 1.;
+constexpr real_t kLsReduction = (real_t)0.1;
+constexpr real_t kLsIncrease = (real_t)1.5;
+constexpr real_t kLsMinAbs = kEqTol;
+constexpr real_t kLsMinRel = (real_t)1.e-14;
+constexpr real_t kLsStatTol = (real_t)1.e-3;
+constexpr real_t kLsMaxStep = (real_t)1.;
+// unit roundoff of real_t
+constexpr double kUnitRoundoff = sizeof(real_t) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
 
 constexpr int kWave = 64;
 
@@ -49,9 +54,9 @@ NMPC_DEV int xref_slot(const BatchView& v, int k) { return ring_wrap(v.xhead + k
 
 // Per-instance base pointers.
 struct Inst {
-    const double* xref; const double* uref;
-    double *C, *c, *zLow, *zUpp, *q, *z, *qStep, *zUnc, *dz, *tmp, *y, *p, *pStep;
-    double *lam, *dl, *grad, *hess, *chol;
+    const real_t* xref; const real_t* uref;
+    real_t *C, *c, *zLow, *zUpp, *q, *z, *qStep, *zUnc, *dz, *tmp, *y, *p, *pStep;
+    real_t *lam, *dl, *grad, *hess, *chol;
     int8_t *ieq, *prev, *chg;
     Scalars* sc;
 };
@@ -86,7 +91,7 @@ NMPC_DEV Inst instance(const BatchView& v, int b) {
     return I;
 }
 
-NMPC_DEV const double* stage_hessian(const BatchView& v, int k) {
+NMPC_DEV const real_t* stage_hessian(const BatchView& v, int k) {
     return k < v.N ? v.H : v.Ht;
 }
 
@@ -99,10 +104,10 @@ NMPC_DEV int wave_max(int x) {
     return x;
 }
 
-NMPC_DEV double wave_min(double x) {
+NMPC_DEV real_t wave_min(real_t x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        double y = __shfl_xor(x, o);
+        real_t y = __shfl_xor(x, o);
         x = y < x ? y : x;
     }
     return x;
@@ -111,8 +116,8 @@ NMPC_DEV double wave_min(double x) {
 // Value held by lane SRC of this lane's 16-lane DPP row (every lane of the row
 // must be active).
 template <int SRC>
-NMPC_DEV double row_bcast(double x) {
-    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, true);
+NMPC_DEV real_t row_bcast(real_t x) {
+    return __builtin_amdgcn_update_dpp((real_t)0.0, x, 0x150 + SRC, 0xf, 0xf, true);
 }
 
 NMPC_DEV double bcast_lane(double x, int src) {   // src must be wave-uniform
@@ -120,10 +125,13 @@ NMPC_DEV double bcast_lane(double x, int src) {   // src must be wave-uniform
     int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
     return __hiloint2double(hi, lo);
 }
+NMPC_DEV float bcast_lane(float x, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
 
 // Clip val to [lo, up], recording the gaps first
 // (stage_qp_solver_clipping.c:174-198).
-NMPC_DEV double clip_gap(double val, double lo, double up, double* y0, double* y1) {
+NMPC_DEV real_t clip_gap(real_t val, real_t lo, real_t up, real_t* y0, real_t* y1) {
     *y0 = lo - val;
     *y1 = val - up;
     if (*y0 >= -kActTol) val = lo;
@@ -134,12 +142,12 @@ NMPC_DEV double clip_gap(double val, double lo, double up, double* y0, double* y
 // 0.5 z'Hz + q'z + p with the reference's accumulation order
 // (dual_qp.c:1552-1559, matrix_vector.c:1887-1900, 2100-2112).  z and q may
 // point to LDS.
-NMPC_DEV double stage_value(const double* H, const double* z, const double* q,
-                            double p, int nV) {
-    double zHz = 0., qz = 0.;
+NMPC_DEV real_t stage_value(const real_t* H, const real_t* z, const real_t* q,
+                            real_t p, int nV) {
+    real_t zHz = 0., qz = 0.;
 #pragma unroll
     for (int i = 0; i < NZ; i++) if (i < nV) zHz += H[i] * z[i] * z[i];
-    double val = 0.5 * zHz;
+    real_t val = 0.5 * zHz;
 #pragma unroll
     for (int i = 0; i < NZ; i++) if (i < nV) qz += q[i] * z[i];
     val += qz;
@@ -152,8 +160,8 @@ NMPC_DEV double stage_value(const double* H, const double* z, const double* q,
 // A row of C is 15 contiguous doubles, 8-byte aligned: fetch it as seven
 // 16-byte loads and one 8-byte load, which halves the number of cache-line
 // look-ups of a wavefront whose lanes each read their own row.
-typedef double pair_u __attribute__((ext_vector_type(2), aligned(8)));
-NMPC_DEV void load_row15(const double* row, double (&out)[NZ]) {
+typedef real_t pair_u __attribute__((ext_vector_type(2), aligned(sizeof(real_t))));
+NMPC_DEV void load_row15(const real_t* row, real_t (&out)[NZ]) {
 #pragma unroll
     for (int j = 0; j + 1 < NZ; j += 2) {
         const pair_u p = *(const pair_u*)(row + j);
@@ -163,12 +171,12 @@ NMPC_DEV void load_row15(const double* row, double (&out)[NZ]) {
     out[NZ - 1] = row[NZ - 1];
 }
 
-NMPC_DEV double gradient_row(const BatchView& v, const Inst& I, const double* zz, int r) {
+NMPC_DEV real_t gradient_row(const BatchView& v, const Inst& I, const real_t* zz, int r) {
     const int k = r / NX, i = r % NX;
     const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);
-    const double* Crow = I.C + (size_t)s * (NX * NZ) + i * NZ;
-    const double* zk = zz + s * NZ;
-    double a = 0.;
+    const real_t* Crow = I.C + (size_t)s * (NX * NZ) + i * NZ;
+    const real_t* zk = zz + s * NZ;
+    real_t a = 0.;
 #pragma unroll
     for (int j = 0; j < NZ; j++) a += Crow[j] * zk[j];
     a += I.c[s * NX + i];

@@ -32,10 +32,10 @@ constexpr int kGroupsPerWave = 4;
 
 using Seq12 = std::make_integer_sequence<int, NX>;
 
-NMPC_DEV double group_min(double x) {
+NMPC_DEV real_t group_min(real_t x) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
-        const double y = __shfl_xor(x, o, 16);
+        const real_t y = __shfl_xor(x, o, 16);
         x = y < x ? y : x;
     }
     return x;
@@ -49,18 +49,19 @@ NMPC_DEV double group_min(double x) {
 // divisors whose significand is all ones; blocks that hold one use plain
 // division.  Checked against n / d on 2.6e10 random and adversarial operand
 // pairs on gfx950 (tools/micro_div.hip): no difference.
-NMPC_DEV bool plain_division_needed(double d) {
+NMPC_DEV bool plain_division_needed(real_t d) {
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: the substitutions divide plainly too
     return true;
 #else
-    return (__double_as_longlong(d) & 0xfffffffffffffLL) == 0xfffffffffffffLL;
+    if constexpr (!kDoublePrecision) return true;   // the fast forms are checked for double only
+    return significand_all_ones((double)d);
 #endif
 }
 template <bool FAST>
-NMPC_DEV double divide(double n, const Pivot& p) {
+NMPC_DEV real_t divide(real_t n, const Pivot& p) {
     if (!FAST) return n / p.d;
-    const double q0 = n * p.y;
-    const double r = __builtin_fma(-p.d, q0, n);
+    const real_t q0 = n * p.y;
+    const real_t r = __builtin_fma(-p.d, q0, n);
     return __builtin_fma(r, p.y, q0);
 }
 
@@ -77,23 +78,23 @@ NMPC_DEV double divide(double n, const Pivot& p) {
 // are made there, between its subtractions (Products q), each pinned in
 // place so that the compiler keeps the interleaving.
 struct Products {
-    double a[NX];   // L[l]  * chol(k,0,l,JJ),     l >= JJ+2
-    double b[NX];   // Ls[l] * chol(k,0,l,JJ),     l >= JJ+2
-    double c[NX];   // Ln[l] * chol(k+1,-1,l,JJ),  all l
+    real_t a[NX];   // L[l]  * chol(k,0,l,JJ),     l >= JJ+2
+    real_t b[NX];   // Ls[l] * chol(k,0,l,JJ),     l >= JJ+2
+    real_t c[NX];   // Ln[l] * chol(k+1,-1,l,JJ),  all l
 };
 
 #define NMPC_PIN(x) asm volatile("" : "+v"(x))
 
 // Item I of the products of column JJ: the twelve c first, then the (a, b) pairs.
 template <int JJ, int I>
-NMPC_DEV void make_product(Products& q, const double (&L)[NX], const double (&Ls)[NX],
-                           const double (&Ln)[NX]) {
+NMPC_DEV void make_product(Products& q, const real_t (&L)[NX], const real_t (&Ls)[NX],
+                           const real_t (&Ln)[NX]) {
     if constexpr (JJ >= 0 && I < NX) {
         q.c[I] = Ln[I] * row_bcast<JJ>(Ln[I]);
         NMPC_PIN(q.c[I]);
     } else if constexpr (JJ >= 0 && JJ + 2 + (I - NX) < NX) {
         constexpr int l = JJ + 2 + (I - NX);
-        const double ljj = row_bcast<JJ>(L[l]);
+        const real_t ljj = row_bcast<JJ>(L[l]);
         q.a[l] = L[l] * ljj;
         q.b[l] = Ls[l] * ljj;
         NMPC_PIN(q.a[l]);
@@ -102,15 +103,15 @@ NMPC_DEV void make_product(Products& q, const double (&L)[NX], const double (&Ls
 }
 
 template <int JJ, int... I>
-NMPC_DEV void make_products(Products& q, const double (&L)[NX], const double (&Ls)[NX],
-                            const double (&Ln)[NX], std::integer_sequence<int, I...>) {
+NMPC_DEV void make_products(Products& q, const real_t (&L)[NX], const real_t (&Ls)[NX],
+                            const real_t (&Ln)[NX], std::integer_sequence<int, I...>) {
     (make_product<JJ, I>(q, L, Ls, Ln), ...);
 }
 
 // Step S of column JJ's chain, followed by item S of the next column's products.
 template <int JJ, int S>
-NMPC_DEV void chain_step(double& sum, double& sub, const Products& p, Products& q,
-                         const double (&L)[NX], const double (&Ls)[NX], const double (&Ln)[NX]) {
+NMPC_DEV void chain_step(real_t& sum, real_t& sub, const Products& p, Products& q,
+                         const real_t (&L)[NX], const real_t (&Ls)[NX], const real_t (&Ln)[NX]) {
     constexpr int nAB = JJ + 2 < NX ? NX - 2 - JJ : 0;
     if constexpr (S < nAB) {
         sum -= p.a[JJ + 2 + S];
@@ -124,8 +125,8 @@ NMPC_DEV void chain_step(double& sum, double& sub, const Products& p, Products& 
 }
 
 template <int JJ, int... S>
-NMPC_DEV void chain_steps(double& sum, double& sub, const Products& p, Products& q,
-                          const double (&L)[NX], const double (&Ls)[NX], const double (&Ln)[NX],
+NMPC_DEV void chain_steps(real_t& sum, real_t& sub, const Products& p, Products& q,
+                          const real_t (&L)[NX], const real_t (&Ls)[NX], const real_t (&Ln)[NX],
                           std::integer_sequence<int, S...>) {
     (chain_step<JJ, S>(sum, sub, p, q, L, Ls, Ln), ...);
 }
@@ -135,12 +136,12 @@ NMPC_DEV void chain_steps(double& sum, double& sub, const Products& p, Products&
 // reciprocal is not good for) shows there as 0xffffffff, and the caller then
 // repeats the block with FAST off.
 template <bool FAST, int JJ>
-NMPC_DEV void factor_column(double (&L)[NX], double (&Ls)[NX], const double (&Ln)[NX],
-                            Products& p, int t, int& failCol, double& diag, uint32_t& ones) {
+NMPC_DEV void factor_column(real_t (&L)[NX], real_t (&Ls)[NX], const real_t (&Ln)[NX],
+                            Products& p, int t, int& failCol, real_t& diag, uint32_t& ones) {
     constexpr int nAB = JJ + 2 < NX ? NX - 2 - JJ : 0;
-    double sum = L[JJ], sub = Ls[JJ];
+    real_t sum = L[JJ], sub = Ls[JJ];
     if constexpr (JJ + 1 < NX) {
-        const double ljj = row_bcast<JJ>(L[JJ + 1]);    // chol(k,0,JJ+1,JJ), just finished
+        const real_t ljj = row_bcast<JJ>(L[JJ + 1]);    // chol(k,0,JJ+1,JJ), just finished
         sum -= L[JJ + 1] * ljj;
         sub -= Ls[JJ + 1] * ljj;
     }
@@ -148,15 +149,15 @@ NMPC_DEV void factor_column(double (&L)[NX], double (&Ls)[NX], const double (&Ln
     chain_steps<JJ>(sum, sub, p, q, L, Ls, Ln, std::make_integer_sequence<int, nAB + NX>{});
     // the next column has one product more than this chain has steps
     make_product<JJ - 1, nAB + NX>(q, L, Ls, Ln);
-    const double piv = row_bcast<JJ>(sum);
+    const real_t piv = row_bcast<JJ>(sum);
     if (failCol < 0 && piv < 1.e2 * kEqTol) failCol = JJ;
-    double d, ld, ls;
+    real_t d, ld, ls;
     if constexpr (FAST) {
         const Pivot pv = root_and_reciprocal(piv);
         d = pv.d;
         ld = divide<true>(sum, pv);
         ls = divide<true>(sub, pv);
-        const uint32_t lo = (uint32_t)__double_as_longlong(d);
+        const uint32_t lo = (uint32_t)__double_as_longlong(pv.d);
         ones = lo > ones ? lo : ones;
     } else {
         d = sqrt(piv);
@@ -170,8 +171,8 @@ NMPC_DEV void factor_column(double (&L)[NX], double (&Ls)[NX], const double (&Ln
 }
 
 template <bool FAST, int... JJ>
-NMPC_DEV void factor_columns(double (&L)[NX], double (&Ls)[NX], const double (&Ln)[NX],
-                             int t, int& failCol, double& diag, uint32_t& ones,
+NMPC_DEV void factor_columns(real_t (&L)[NX], real_t (&Ls)[NX], const real_t (&Ln)[NX],
+                             int t, int& failCol, real_t& diag, uint32_t& ones,
                              std::integer_sequence<int, JJ...>) {
     // The last block row has nothing below it: Ln is zero there, and taking
     // +0 away leaves a sum as it is, so its c terms need no branch around them.
@@ -182,21 +183,21 @@ NMPC_DEV void factor_columns(double (&L)[NX], double (&Ls)[NX], const double (&L
 
 // Row R of the bottom-up substitution L' x = g for block k (dual_qp.c:1003-1026).
 template <bool FAST, int R>
-NMPC_DEV void backsolve_row(double (&xk)[NX], double& mine, const double (&L)[NX],
-                            const double (&pn)[NX], double g, const Pivot& dd, int t) {
-    double sum = g;
+NMPC_DEV void backsolve_row(real_t (&xk)[NX], real_t& mine, const real_t (&L)[NX],
+                            const real_t (&pn)[NX], real_t g, const Pivot& dd, int t) {
+    real_t sum = g;
 #pragma unroll
     for (int j = R + 1; j < NX; ++j) sum -= L[j] * xk[j];
 #pragma unroll
     for (int j = 0; j < NX; ++j) sum -= pn[j];          // +0 in the last block row
-    const double x = divide<FAST>(sum, dd);
+    const real_t x = divide<FAST>(sum, dd);
     xk[R] = row_bcast<R>(x);
     mine = (t == R) ? x : mine;
 }
 
 template <bool FAST, int... R>
-NMPC_DEV void backsolve_rows(double (&xk)[NX], double& mine, const double (&L)[NX],
-                             const double (&pn)[NX], double g, const Pivot& dd, int t,
+NMPC_DEV void backsolve_rows(real_t (&xk)[NX], real_t& mine, const real_t (&L)[NX],
+                             const real_t (&pn)[NX], real_t g, const Pivot& dd, int t,
                              std::integer_sequence<int, R...>) {
     (backsolve_row<FAST, NX - 1 - R>(xk, mine, L, pn, g, dd, t), ...);
 }
@@ -205,18 +206,18 @@ NMPC_DEV void backsolve_rows(double (&xk)[NX], double& mine, const double (&L)[N
 // (dual_qp.c:1029-1052), column-oriented: once x_J is final every later row
 // subtracts its L(i,J) x_J, which keeps each row's terms in ascending J order.
 template <bool FAST, int J>
-NMPC_DEV void forward_column(double (&xk)[NX], double& mine, double& sum,
-                             const double (&Ld)[NX], const Pivot& dd, int t) {
-    const double x = divide<FAST>(sum, dd);
-    const double xj = row_bcast<J>(x);
+NMPC_DEV void forward_column(real_t (&xk)[NX], real_t& mine, real_t& sum,
+                             const real_t (&Ld)[NX], const Pivot& dd, int t) {
+    const real_t x = divide<FAST>(sum, dd);
+    const real_t xj = row_bcast<J>(x);
     xk[J] = xj;
     mine = (t == J) ? x : mine;
     sum -= Ld[J] * xj;
 }
 
 template <bool FAST, int... J>
-NMPC_DEV void forward_columns(double (&xk)[NX], double& mine, double& sum,
-                              const double (&Ld)[NX], const Pivot& dd, int t,
+NMPC_DEV void forward_columns(real_t (&xk)[NX], real_t& mine, real_t& sum,
+                              const real_t (&Ld)[NX], const Pivot& dd, int t,
                               std::integer_sequence<int, J...>) {
     (forward_column<FAST, J>(xk, mine, sum, Ld, dd, t), ...);
 }
@@ -226,7 +227,7 @@ NMPC_DEV void forward_columns(double (&xk)[NX], double& mine, double& sum,
 // address, so the LDS base handed over makes up the difference.
 typedef __attribute__((address_space(3))) char* lds_bytes;
 template <int... Lrow>
-NMPC_DEV void fetch_rows_to_lds(const double* g0, lds_bytes image, std::integer_sequence<int, Lrow...>) {
+NMPC_DEV void fetch_rows_to_lds(const real_t* g0, lds_bytes image, std::integer_sequence<int, Lrow...>) {
     (__builtin_amdgcn_global_load_lds(
          (const __attribute__((address_space(1))) void*)g0,
          (__attribute__((address_space(3))) void*)(image + Lrow * (1024 - 192)), 16, Lrow * 192, 0),
@@ -234,8 +235,8 @@ NMPC_DEV void fetch_rows_to_lds(const double* g0, lds_bytes image, std::integer_
 }
 
 // Entry t of a 12-vector held in registers, t known only at run time.
-NMPC_DEV double L_diag(const double (&L)[NX], int t) {
-    double d = L[0];
+NMPC_DEV real_t L_diag(const real_t (&L)[NX], int t) {
+    real_t d = L[0];
 #pragma unroll
     for (int l = 1; l < NX; l++) d = (t == l) ? L[l] : d;
     return d;
@@ -258,12 +259,12 @@ NMPC_DEV double L_diag(const double (&L)[NX], int t) {
 // diagonal block (entry 12 + t).
 template <bool STAGED>
 NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool active, int t,
-                           double& minDiag) {
+                           real_t& minDiag) {
     const int N = v.N;
     const bool col = t < NX;
     const int tc = col ? t : 0;
     int status = ST_OK;
-    double Ln[NX], pn[NX], xk[NX];      // pn[j] = chol(k+1,-1,j,t) * x_{k+1}[j]
+    real_t Ln[NX], pn[NX], xk[NX];      // pn[j] = chol(k+1,-1,j,t) * x_{k+1}[j]
 #pragma unroll
     for (int j = 0; j < NX; j++) { Ln[j] = 0.; pn[j] = 0.; xk[j] = 0.; }
 
@@ -274,10 +275,10 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
     // have read back, and the columns need no per-lane choice between a computed
     // and a fetched value.  Groups whose results are dropped fetch nothing and
     // work on zeros.
-    __shared__ double rows[STAGED ? NX * kWave * 2 : 1];
+    __shared__ real_t rows[STAGED ? NX * kWave * 2 : 1];
     const lds_bytes image = (lds_bytes)rows;
     const int slot = (threadIdx.x >> 4) * 32;           // this group's part of a row image
-    double nL[STAGED ? 1 : NX], nLs[STAGED ? 1 : NX], ng = 0., nd = 1.;
+    real_t nL[STAGED ? 1 : NX], nLs[STAGED ? 1 : NX], ng = 0., nd = 1.;
     if constexpr (STAGED) {
         if (!active) {
 #pragma unroll
@@ -291,9 +292,9 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         for (int l = 0; l < NX; l++) { nL[l] = 0.; nLs[l] = 0.; }
     }
     auto fetch_block_row = [&](bool fromH, int kk) {
-        const double* src = fromH ? I.hess : I.chol;
+        const real_t* src = fromH ? I.hess : I.chol;
         if constexpr (STAGED) {
-            const double* g0 = src + (size_t)kk * (2 * NX * NX) + 2 * tc;
+            const real_t* g0 = src + (size_t)kk * (2 * NX * NX) + 2 * tc;
             if (active && col) fetch_rows_to_lds(g0, image, Seq12{});
             if (active) ng = I.grad[kk * NX + tc];
         } else if (active) {
@@ -312,8 +313,8 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
     for (int k = N - 1; k >= 0; --k) {
         const bool fromHess = nextFromHess;
         const bool factorThis = active && status == ST_OK && k <= start;
-        double L[NX], Ls[NX];
-        double dd;                                      // chol(k,0,t,t) unless refactorised below
+        real_t L[NX], Ls[NX];
+        real_t dd;                                      // chol(k,0,t,t) unless refactorised below
         if constexpr (STAGED) {
             // the block row fetched during the last iteration has landed ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -330,7 +331,7 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
             for (int l = 0; l < NX; l++) { L[l] = nL[l]; Ls[l] = nLs[l]; }
             dd = nd;
         }
-        const double g = ng;
+        const real_t g = ng;
         if (k > 0) {
             // a failure in this block is not known yet; a group that fails stops
             // using its results, so the guess "still factorising" is harmless
@@ -340,11 +341,13 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         if (fromHess) {
             int failCol = -1;
             uint32_t ones = 0;
-            factor_columns<true>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
+            // (single precision takes roots and quotients plainly: the fast forms are
+            // checked for double only)
+            factor_columns<kDoublePrecision>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: exercise the repeat path on every block
             ones = 0xffffffffu;
 #endif
-            if (__any(ones == 0xffffffffu)) {
+            if (kDoublePrecision && __any(ones == 0xffffffffu)) {
                 if (active) {
 #pragma unroll
                     for (int l = 0; l < NX; l++) {
@@ -374,7 +377,7 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         if (col && minDiag > dd) minDiag = dd;
 
         // bottom-up substitution, block k
-        double mine = 0.;
+        real_t mine = 0.;
         const Pivot pv{dd, 1.0 / dd};
         if (__any(plain_division_needed(dd)))
             backsolve_rows<false>(xk, mine, L, pn, g, pv, t, Seq12{});
@@ -396,11 +399,11 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
     const int N = v.N;
     const bool col = t < NX;
     const int tc = col ? t : 0;
-    double xk[NX], xo[NX];
+    real_t xk[NX], xo[NX];
 #pragma unroll
     for (int j = 0; j < NX; j++) { xk[j] = 0.; xo[j] = 0.; }
-    double norm2 = 0.;
-    double nLd[NX], nLr[NX], nsum = 0., nd = 1.;
+    real_t norm2 = 0.;
+    real_t nLd[NX], nLr[NX], nsum = 0., nd = 1.;
 #pragma unroll
     for (int j = 0; j < NX; j++) { nLd[j] = 0.; nLr[j] = 0.; }
     if (live) {
@@ -410,11 +413,11 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
         nd = HS(I.chol, 0, 0, tc, tc);
     }
     for (int k = 0; k < N; ++k) {
-        double Ld[NX], Lr[NX];
+        real_t Ld[NX], Lr[NX];
 #pragma unroll
         for (int j = 0; j < NX; j++) { Ld[j] = nLd[j]; Lr[j] = nLr[j]; }
-        double sum = nsum;
-        const double dd = nd;
+        real_t sum = nsum;
+        const real_t dd = nd;
         if (k + 1 < N && live) {
 #pragma unroll
             for (int j = 0; j < NX; j++) {
@@ -428,7 +431,7 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 #pragma unroll
             for (int j = 0; j < NX; ++j) sum -= Lr[j] * xo[j];
         }
-        double mine = 0.;
+        real_t mine = 0.;
         const Pivot pv{dd, 1.0 / dd};
         if (__any(plain_division_needed(dd)))
             forward_columns<false>(xk, mine, sum, Ld, pv, t, Seq12{});
@@ -466,7 +469,7 @@ void k_newton_solve(BatchView v) {
     bool sweep = live;
     int from = start;
     for (int pass = 0; pass < 2; ++pass) {
-        double minDiag = kInfty;
+        real_t minDiag = kInfty;
         const int st = backward_pass<WAVES == 2>(v, I, from, sweep, t, minDiag);
         if (pass == 0) {
             minDiag = group_min(minDiag);
@@ -493,10 +496,11 @@ void k_newton_solve(BatchView v) {
 // (0.77 ms instead of 0.55 ms per launch at 4096 instances).
 void launch_newton_solve(const BatchView& v, hipStream_t s) {
     const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
+    // (the staged form's LDS image is laid out for 8-byte entries)
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds take the staged form at every size
-    const bool two = true;
+    const bool two = kDoublePrecision;
 #else
-    const bool two = blocks > kOneWavePerSimd * 3 / 2;
+    const bool two = kDoublePrecision && blocks > kOneWavePerSimd * 3 / 2;
 #endif
     if (two) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
     else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);

@@ -48,18 +48,18 @@ constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920: z + q, reused as su
 
 // dynamic LDS: buf[1920] | vals[N+1] | red[8] | chg[N+1] (int)
 struct StageLds {
-    double* z;      // [64*15]
-    double* q;      // [64*15]
-    double* buf;    // = z, 1920 doubles for ordered sums
-    double* vals;   // [N+1] stage objective values by slot
-    double* red;    // [8]
+    real_t* z;      // [64*15]
+    real_t* q;      // [64*15]
+    real_t* buf;    // = z, 1920 doubles for ordered sums
+    real_t* vals;   // [N+1] stage objective values by slot
+    real_t* red;    // [8]
     int* chg;       // [N+1] active set of slot changed
-    double* terms;  // [12 N] slope terms of the fused sweep (k_newton_step), or null
-    double* sqr;    // [12 N] squared gradient rows of the same sweep
-    double* prevz;  // [15] clipped point of the stage before the current chunk
+    real_t* terms;  // [12 N] slope terms of the fused sweep (k_newton_step), or null
+    real_t* sqr;    // [12 N] squared gradient rows of the same sweep
+    real_t* prevz;  // [15] clipped point of the stage before the current chunk
 };
 
-NMPC_DEV StageLds carve(double* base, int N) {
+NMPC_DEV StageLds carve(real_t* base, int N) {
     StageLds L;
     L.z = base;
     L.q = base + kStageChunk * NZ;
@@ -76,10 +76,10 @@ NMPC_DEV StageLds carve(double* base, int N) {
 // k_newton_step: room for the slope terms its first sweep produces on the way,
 // when the gradient fits one accumulation buffer.
 NMPC_DEV bool sweep_has_slope(int N) { return NX * N <= kBufDoubles; }
-NMPC_DEV StageLds carve_step(double* base, int N) {
+NMPC_DEV StageLds carve_step(real_t* base, int N) {
     StageLds L = carve(base, N);
     if (sweep_has_slope(N)) {
-        L.prevz = (double*)L.chg + ((size_t)(N + 1) * sizeof(int) + 7) / 8;
+        L.prevz = (real_t*)L.chg + ((size_t)(N + 1) * sizeof(int) + 7) / 8 * (8 / sizeof(real_t));
         L.terms = L.prevz + 16;
         L.sqr = L.terms + NX * N;
     }
@@ -87,11 +87,11 @@ NMPC_DEV StageLds carve_step(double* base, int N) {
 }
 
 inline size_t stage_lds_bytes(int N) {
-    return (size_t)(kBufDoubles + (N + 1) + 8) * sizeof(double) + (size_t)(N + 1) * sizeof(int);
+    return (size_t)(kBufDoubles + (N + 1) + 8) * sizeof(real_t) + (size_t)(N + 1) * sizeof(int);
 }
 inline size_t step_lds_bytes(int N) {
     const size_t base = (stage_lds_bytes(N) + 7) / 8 * 8;
-    return base + (NX * N <= kBufDoubles ? (size_t)(16 + 2 * NX * N) * sizeof(double) : 0);
+    return base + (NX * N <= kBufDoubles ? (size_t)(16 + 2 * NX * N) * sizeof(real_t) : 0);
 }
 
 // acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order, by
@@ -112,23 +112,29 @@ NMPC_DEV void add_row_value(double& acc, double x, double one) {
                  : "+v"(acc)
                  : "v"(x), "v"(one), "n"(SRC));
 }
+template <int SRC>
+NMPC_DEV void add_row_value(float& acc, float x, float one) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(x), "v"(one), "n"(SRC));
+}
 template <int... I>
-NMPC_DEV void add_row_block(double& acc, const double (&c)[4], double one,
+NMPC_DEV void add_row_block(real_t& acc, const real_t (&c)[4], real_t one,
                             std::integer_sequence<int, I...>) {
     (add_row_value<I / 4>(acc, c[I % 4], one), ...);
 }
 template <int... I>
-NMPC_DEV void add_row_block_partial(double& acc, const double (&c)[4], double one, int count,
+NMPC_DEV void add_row_block_partial(real_t& acc, const real_t (&c)[4], real_t one, int count,
                                     std::integer_sequence<int, I...>) {
     ((I < count ? add_row_value<I / 4>(acc, c[I % 4], one) : (void)0), ...);
 }
-NMPC_DEV double accumulate_by_row(double acc, const double* buf, int len) {
+NMPC_DEV real_t accumulate_by_row(real_t acc, const real_t* buf, int len) {
     using Seq64 = std::make_integer_sequence<int, 64>;
     const int l = threadIdx.x & 15;
-    double one = 1.0;
+    real_t one = 1.0;
     asm volatile("" : "+v"(one));               // keeps it in a vector register pair
-    double c[4], nx[4];
-    auto fetch = [&](double (&d)[4], int t) {
+    real_t c[4], nx[4];
+    auto fetch = [&](real_t (&d)[4], int t) {
 #pragma unroll
         for (int i = 0; i < 4; i++) d[i] = (t + 4 * l + i < len) ? buf[t + 4 * l + i] : 0.;
     };
@@ -147,15 +153,15 @@ NMPC_DEV double accumulate_by_row(double acc, const double* buf, int len) {
 // Sum term(0) + ... + term(n-1) in index order starting from 0.  Terms are
 // produced by all threads; wavefront 0 accumulates.  Uniform result.
 template <class F>
-NMPC_DEV double block_ordered_sum(int n, const StageLds& L, F term) {
+NMPC_DEV real_t block_ordered_sum(int n, const StageLds& L, F term) {
     const int tid = threadIdx.x;
-    double acc = 0.;
+    real_t acc = 0.;
     for (int base = 0; base < n; base += kBufDoubles) {
         const int len = (n - base < kBufDoubles) ? n - base : kBufDoubles;
         int r = tid;
         for (; r + kStageThreads < len; r += 2 * kStageThreads) {   // two terms in flight
-            const double t0 = term(base + r);
-            const double t1 = term(base + r + kStageThreads);
+            const real_t t0 = term(base + r);
+            const real_t t1 = term(base + r + kStageThreads);
             L.buf[r] = t0;
             L.buf[r + kStageThreads] = t1;
         }
@@ -166,17 +172,17 @@ NMPC_DEV double block_ordered_sum(int n, const StageLds& L, F term) {
     }
     if (tid == 0) L.red[0] = acc;
     __syncthreads();
-    const double out = L.red[0];
+    const real_t out = L.red[0];
     __syncthreads();
     return out;
 }
 
-NMPC_DEV double block_min(double x, const StageLds& L) {
+NMPC_DEV real_t block_min(real_t x, const StageLds& L) {
     x = wave_min(x);
     const int tid = threadIdx.x;
     if ((tid & 63) == 0) L.red[1 + (tid >> 6)] = x;
     __syncthreads();
-    double m = L.red[1];
+    real_t m = L.red[1];
 #pragma unroll
     for (int w = 1; w < kStageThreads / kWave; w++) m = (L.red[1 + w] < m) ? L.red[1 + w] : m;
     __syncthreads();
@@ -207,7 +213,7 @@ enum PassMode { kBegin, kCommit, kTrialValue, kTrialPoint };
 //   kTrialPoint       clipped trial point into tmp, gaps into y (dual_qp.c:1370-1376);
 //                     returns 0
 template <PassMode MODE>
-NMPC_DEV double stage_pass(const BatchView& v, const Inst& I, double a, const StageLds& L) {
+NMPC_DEV real_t stage_pass(const BatchView& v, const Inst& I, real_t a, const StageLds& L) {
     const int tid = threadIdx.x, N = v.N;
     const int eEnd = NZ * N + NX;            // terminal slot holds 12 variables
     for (int c0 = 0; c0 <= N; c0 += kStageChunk) {
@@ -215,17 +221,17 @@ NMPC_DEV double stage_pass(const BatchView& v, const Inst& I, double a, const St
         const int e0 = c0 * NZ;
         const int e1 = (c1 * NZ < eEnd) ? c1 * NZ : eEnd;
         for (int e = e0 + tid; e < e1; e += kStageThreads) {
-            const double zu = I.zUnc[e] + a * I.dz[e];
+            const real_t zu = I.zUnc[e] + a * I.dz[e];
             if (MODE == kBegin || MODE == kCommit) I.zUnc[e] = zu;
-            double y0, y1;
-            const double zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
+            real_t y0, y1;
+            const real_t zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
             I.y[2 * e] = y0;
             I.y[2 * e + 1] = y1;
             if (MODE == kTrialPoint) {
                 I.tmp[e] = zc;
             } else {
                 I.z[e] = zc;
-                const double qv = I.q[e] + a * I.qStep[e];
+                const real_t qv = I.q[e] + a * I.qStep[e];
                 if (MODE != kTrialValue) I.q[e] = qv;
                 L.z[e - e0] = zc;
                 L.q[e - e0] = qv;
@@ -248,8 +254,8 @@ NMPC_DEV double stage_pass(const BatchView& v, const Inst& I, double a, const St
         if (MODE != kTrialPoint) {
             for (int s = c0 + tid; s < c1; s += kStageThreads) {
                 const int nV = s < N ? NZ : NX;
-                const double* H = s < N ? v.H : v.Ht;
-                const double pt = I.p[s] + a * I.pStep[s];
+                const real_t* H = s < N ? v.H : v.Ht;
+                const real_t pt = I.p[s] + a * I.pStep[s];
                 if (MODE != kTrialValue) I.p[s] = pt;
                 L.vals[s] = stage_value(H, L.z + (s - c0) * NZ, L.q + (s - c0) * NZ, pt, nV);
             }
@@ -260,13 +266,13 @@ NMPC_DEV double stage_pass(const BatchView& v, const Inst& I, double a, const St
     // objective: stage values summed in horizon order
     if (tid < kWave) {
         // vals is slot-ordered: positions 0..N-1 are slots head..N-1, 0..head-1, then slot N
-        double acc = accumulate_by_row(0., L.vals + v.head, N - v.head);
+        real_t acc = accumulate_by_row(0., L.vals + v.head, N - v.head);
         acc = accumulate_by_row(acc, L.vals, v.head);
         acc += L.vals[N];
         if (tid == 0) L.red[0] = acc;
     }
     __syncthreads();
-    const double obj = L.red[0];
+    const real_t obj = L.red[0];
     __syncthreads();
     return obj;
 }
@@ -294,19 +300,19 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
 // step stored it).
 // Returns false when the gradient norm passes the convergence test.
 NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& L, int it,
-                             bool gradKept, const double* normKept = nullptr) {
+                             bool gradKept, const real_t* normKept = nullptr) {
     const int tid = threadIdx.x, N = v.N;
-    double nn;
+    real_t nn;
     if (gradKept && normKept) {
         nn = *normKept;
     } else if (gradKept) {
         nn = block_ordered_sum(NX * N, L, [&](int r) {
-            const double g = I.grad[r];
+            const real_t g = I.grad[r];
             return g * g;
         });
     } else {
         nn = block_ordered_sum(NX * N, L, [&](int r) {
-            const double g = gradient_row(v, I, I.z, r);
+            const real_t g = gradient_row(v, I, I.z, r);
             I.grad[r] = g;
             return g * g;
         });
@@ -322,18 +328,18 @@ NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& 
 // Newton Hessian block rows of the stages whose active set changed, every
 // WAVES-th block row per wavefront; slices: 360 doubles of LDS per wavefront.
 template <int WAVES>
-NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices) {
+NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices) {
     const int tid = threadIdx.x, N = v.N;
     const int w = tid >> 6, lane = tid & 63;
-    double* Cs = slices + w * (2 * NX * NZ);
-    double* Zs = Cs + NX * NZ;
+    real_t* Cs = slices + w * (2 * NX * NZ);
+    real_t* Zs = Cs + NX * NZ;
     // The Jacobian entries and gaps of the next block row to assemble are fetched
     // while the current one is worked on.
-    struct Fetched { double c[3], y[4]; };
+    struct Fetched { real_t c[3], y[4]; };
     auto needed = [&](int k) { return k < N && (I.chg[k] != 0 || I.chg[k + 1] != 0); };
     auto fetch = [&](int k, Fetched& f) {
         const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);
-        const double* Cg = I.C + (size_t)s * (NX * NZ);
+        const real_t* Cg = I.C + (size_t)s * (NX * NZ);
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int e = lane + t * kWave;
@@ -354,7 +360,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
         while (kn < N && !needed(kn)) kn += WAVES;
         if (kn < N) fetch(kn, nxt);
         const bool ck = I.chg[k] != 0;
-        const double* Hn = stage_hessian(v, k + 1);
+        const real_t* Hn = stage_hessian(v, k + 1);
         // free columns of stage k; fixed states of stage k+1
         const bool fr = lane < NZ && cur.y[0] <= kEqTol && cur.y[1] <= kEqTol;
         const bool fx = lane < NX && (cur.y[2] >= kEqTol || cur.y[3] >= kEqTol);
@@ -377,7 +383,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
         // diagonal block: E P_{k+1} E' + C_k P_k C_k'
         if (lane < 48) {
             const int i = lane >> 2, j0 = (lane & 3) * 3;
-            double m[3];
+            real_t m[3];
 #pragma unroll
             for (int t = 0; t < 3; t++) {
                 m[t] = 0.;
@@ -388,11 +394,11 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
             }
             for (int l = 0; l < NZ; l++) {
                 if (!((freeMask >> l) & 1ull)) continue;
-                const double ci = Cs[i * NZ + l];
+                const real_t ci = Cs[i * NZ + l];
 #pragma unroll
                 for (int t = 0; t < 3; t++) m[t] += ci * Zs[l * NX + j0 + t];
             }
-            double* Hd = I.hess + (size_t)k * 2 * NX * NX + i * 2 * NX + NX + j0;
+            real_t* Hd = I.hess + (size_t)k * 2 * NX * NX + i * 2 * NX + NX + j0;
 #pragma unroll
             for (int t = 0; t < 3; t++) Hd[t] = m[t];
         }
@@ -400,7 +406,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
         if (k >= 1 && ck) {
             for (int e = lane; e < NX * NX; e += kWave) {
                 const int i = e / NX, j = e % NX;
-                const double val = Cs[i * NZ + j] / v.H[j];
+                const real_t val = Cs[i * NZ + j] / v.H[j];
                 I.hess[(size_t)k * 2 * NX * NX + i * 2 * NX + j] =
                     ((freeMask >> j) & 1ull) ? -val : 0.;
             }
@@ -414,7 +420,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, double* slices
 }
 
 NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it,
-                           bool gradKept = false, const double* normKept = nullptr) {
+                           bool gradKept = false, const real_t* normKept = nullptr) {
     if (setup_gradient(v, I, L, it, gradKept, normKept))
         assemble_hessian<kStageThreads / kWave>(v, I, L.buf);
 }
@@ -424,8 +430,8 @@ NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L,
 // machine: trial_alpha() names the next trial step, advance() consumes its
 // slope.  Phase 0 grows the bracket from its upper end, phase 1 bisects it.
 struct Bisection {
-    double aMin, aMax, aMid;
-    double alpha;       // result, valid when done
+    real_t aMin, aMax, aMid;
+    real_t alpha;       // result, valid when done
     int it;             // line-search trial counter (shared with the backtracking phase)
     int phase;
     bool done;
@@ -439,11 +445,11 @@ NMPC_DEV void settle(Bisection& s) {
     }
 }
 
-NMPC_DEV double trial_alpha(const Bisection& s) {
+NMPC_DEV real_t trial_alpha(const Bisection& s) {
     return s.phase == 0 ? s.aMax : 0.5 * (s.aMin + s.aMax);
 }
 
-NMPC_DEV void advance(Bisection& s, double slope, double normal) {
+NMPC_DEV void advance(Bisection& s, real_t slope, real_t normal) {
     if (s.phase == 0) {
         if (fabs(slope / normal) <= kLsStatTol) { s.alpha = s.aMax; s.done = true; return; }
         if (slope / normal < 0.) { s.phase = 1; settle(s); return; }
@@ -488,11 +494,11 @@ NMPC_DEV void advance_decided(Bisection& s, bool flat, bool negative) {
 // of the true sum, so a tree sum s and the magnitude sum m settle both
 // questions for the row-order sum too whenever |s| is further from the
 // threshold than twice that bound (taken generously, with room for the rounding
-// of m, of the threshold and of the quotient).  Otherwise the caller adds the
+// of m, of the threshold and of the quotient: 64 units roundoff of the threshold).  Otherwise the caller adds the
 // terms in order.
-NMPC_DEV bool slope_decided(double s, double m, int n, double normal, bool* flat, bool* negative) {
-    const double thr = kLsStatTol * normal;
-    const double slack = 4.0 * (double)n * 1.1102230246251565e-16 * m + 1e-12 * thr;
+NMPC_DEV bool slope_decided(real_t s, real_t m, int n, real_t normal, bool* flat, bool* negative) {
+    const real_t thr = kLsStatTol * normal;
+    const real_t slack = (real_t)(4.0 * (double)n * kUnitRoundoff * (double)m + 64.0 * kUnitRoundoff * (double)thr);
     *flat = fabs(s) < thr;
     *negative = s < 0.;
     return fabs(fabs(s) - thr) > slack;         // false for NaN operands as well
@@ -521,13 +527,13 @@ NMPC_DEV void advance_assuming(Bisection& s, bool negative) {
 // what is left is the unclipped point, the linear term, the offsets and the
 // active-set record.  Every value is produced by the expression the full pass
 // uses, so the state is the one stage_pass<kCommit> would leave.
-NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, double a, const StageLds& L) {
+NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, real_t a, const StageLds& L) {
     const int tid = threadIdx.x, N = v.N;
     const int eEnd = NZ * N + NX;
     for (int e = tid; e < eEnd; e += kStageThreads) {
         I.zUnc[e] = I.zUnc[e] + a * I.dz[e];
         I.q[e] = I.q[e] + a * I.qStep[e];
-        const double y0 = I.y[2 * e], y1 = I.y[2 * e + 1];
+        const real_t y0 = I.y[2 * e], y1 = I.y[2 * e + 1];
         const int s = e / NZ, i = e - s * NZ;
         const int idx = slot_position(v, s) * NZ + i;
         const int8_t code = (y0 > kEqTol) ? -1 : ((y1 > kEqTol) ? 1 : 0);
@@ -543,16 +549,16 @@ NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, double a, con
 // Commit of the chosen step: multipliers, stage variables, objective, active
 // sets; then the Newton set-up of iteration nextIt.  keptObjective points to the
 // objective of the value trial that z and y still hold, or is null.
-NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, double alpha,
-                          int lsIter, int nextIt, const double* keptObjective = nullptr,
+NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, real_t alpha,
+                          int lsIter, int nextIt, const real_t* keptObjective = nullptr,
                           bool gradKept = false, bool withHessian = true,
-                          const double* normKept = nullptr) {
+                          const real_t* normKept = nullptr) {
     const int tid = threadIdx.x, n = NX * v.N;
     for (int r = tid; r < n; r += kStageThreads) {
-        double* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
+        real_t* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
         *lp = *lp + alpha * I.dl[r];
     }
-    double objInc;
+    real_t objInc;
     if (keptObjective) {
         commit_kept_trial(v, I, alpha, L);
         objInc = *keptObjective;
@@ -586,23 +592,23 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
 // time; the rows of a stage are done once its successor's point is known.
 // Returns the trial objective; *aminOut the smallest step; with L.terms:
 // *slopeOut the slope at the full step, and grad is written when keepGrad.
-NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I, const StageLds& L,
-                                               bool keepGrad, double* aminOut, double* slopeOut,
-                                               double* normOut) {
+NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I, const StageLds& L,
+                                               bool keepGrad, real_t* aminOut, real_t* slopeOut,
+                                               real_t* normOut) {
     const int tid = threadIdx.x, N = v.N;
-    const double a = 1.;
+    const real_t a = 1.;
     const bool rows = L.terms != nullptr;
-    double amin = kInfty;
+    real_t amin = kInfty;
     for (int c0 = 0; c0 <= N; c0 += kStageChunk) {
         const int c1 = (c0 + kStageChunk <= N + 1) ? c0 + kStageChunk : N + 1;
         for (int idx = tid; idx < (c1 - c0) * NZ; idx += kStageThreads) {
             const int kk = idx / NZ, j = idx - kk * NZ, k = c0 + kk;
             if (k == N && j >= NX) continue;
             const int s = stage_slot(v, k), e = s * NZ + j;
-            double qs;
+            real_t qs;
             if (k < N) {
-                const double* Cc = I.C + (size_t)s * (NX * NZ) + j;
-                const double* l1 = I.dl + k * NX;
+                const real_t* Cc = I.C + (size_t)s * (NX * NZ) + j;
+                const real_t* l1 = I.dl + k * NX;
                 qs = 0.;
 #pragma unroll
                 for (int i = 0; i < NX; i++) qs += Cc[i * NZ] * l1[i];
@@ -611,17 +617,17 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
             }
             if (k > 0 && j < NX) qs -= I.dl[(k - 1) * NX + j];
             I.qStep[e] = qs;
-            const double d = qs / (k < N ? v.H[j] : v.Ht[j]);
-            const double dzv = -d;
+            const real_t d = qs / (k < N ? v.H[j] : v.Ht[j]);
+            const real_t dzv = -d;
             I.dz[e] = dzv;
-            const double r0 = dzv / I.y[2 * e];
-            const double r1 = dzv / -I.y[2 * e + 1];
-            const double aa = 1. / ((r0 > r1) ? r0 : r1);
+            const real_t r0 = dzv / I.y[2 * e];
+            const real_t r1 = dzv / -I.y[2 * e + 1];
+            const real_t aa = 1. / ((r0 > r1) ? r0 : r1);
             if (aa > 0. && aa < amin) amin = aa;
             // value trial at the full step
-            const double zu = I.zUnc[e] + a * dzv;
-            double y0, y1;
-            const double zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
+            const real_t zu = I.zUnc[e] + a * dzv;
+            real_t y0, y1;
+            const real_t zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
             I.y[2 * e] = y0;
             I.y[2 * e + 1] = y1;
             I.z[e] = zc;
@@ -631,16 +637,16 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
         __syncthreads();
         for (int k = c0 + tid; k < c1; k += kStageThreads) {
             const int s = stage_slot(v, k);
-            double ps = 0.;
+            real_t ps = 0.;
             if (k < N) {
-                const double* l1 = I.dl + k * NX;
+                const real_t* l1 = I.dl + k * NX;
 #pragma unroll
                 for (int i = 0; i < NX; i++) ps += l1[i] * I.c[s * NX + i];
             }
             I.pStep[s] = ps;
             const int nV = k < N ? NZ : NX;
-            const double* H = k < N ? v.H : v.Ht;
-            const double pt = I.p[s] + a * ps;
+            const real_t* H = k < N ? v.H : v.Ht;
+            const real_t pt = I.p[s] + a * ps;
             L.vals[k] = stage_value(H, L.z + (k - c0) * NZ, L.q + (k - c0) * NZ, pt, nV);
         }
         if (rows) {
@@ -649,9 +655,9 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
             for (int rr = tid; rr < (c1 - 1 - kFirst) * NX; rr += kStageThreads) {
                 const int kk = rr / NX, i = rr - kk * NX, k = kFirst + kk;
                 const int s = stage_slot(v, k);
-                const double* Crow = I.C + (size_t)s * (NX * NZ) + i * NZ;
-                const double* zk = (k >= c0) ? L.z + (k - c0) * NZ : L.prevz;
-                double g = 0.;
+                const real_t* Crow = I.C + (size_t)s * (NX * NZ) + i * NZ;
+                const real_t* zk = (k >= c0) ? L.z + (k - c0) * NZ : L.prevz;
+                real_t g = 0.;
 #pragma unroll
                 for (int j = 0; j < NZ; j++) g += Crow[j] * zk[j];
                 g += I.c[s * NX + i];
@@ -671,12 +677,12 @@ NMPC_DEV double directions_and_full_step_trial(const BatchView& v, const Inst& I
     // side by side
     if (tid < 3 * 16) {             // one DPP row each
         const int w = tid >> 4;
-        const double* src = (w == 0 || !rows) ? L.vals : (w == 1 ? L.terms : L.sqr);
-        const double sv = accumulate_by_row(0., src, (w == 0 || !rows) ? N + 1 : NX * N);
+        const real_t* src = (w == 0 || !rows) ? L.vals : (w == 1 ? L.terms : L.sqr);
+        const real_t sv = accumulate_by_row(0., src, (w == 0 || !rows) ? N + 1 : NX * N);
         if ((tid & 15) == 0) L.red[w] = sv;
     }
     __syncthreads();
-    const double obj = L.red[0];
+    const real_t obj = L.red[0];
     *slopeOut = L.red[1];
     *normOut = L.red[2];
     __syncthreads();                            // block_min reuses red[1..]
@@ -702,14 +708,14 @@ NMPC_DEV bool tail_capable(const BatchView& v) {
     return v.tailList != nullptr && v.N <= kTailMaxHorizon;
 }
 inline size_t tail_lds_bytes(int N) {
-    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(double) + 256;
+    return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(real_t) + 256;
 }
 }  // namespace
 
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(BatchView v,
-                                                            const double* __restrict__ meas) {
-    extern __shared__ double lds_raw[];
+                                                            const real_t* __restrict__ meas) {
+    extern __shared__ real_t lds_raw[];
     const StageLds L = carve(lds_raw, v.N);
     const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
@@ -717,8 +723,8 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
 
     // initial-value embedding: pin the stage-0 state to the measured deviation
     if (tid == 0) {
-        double x0[NS], m[NS], d[NX];
-        const double* xr = I.xref + (size_t)xref_slot(v, 0) * NS;
+        real_t x0[NS], m[NS], d[NX];
+        const real_t* xr = I.xref + (size_t)xref_slot(v, 0) * NS;
 #pragma unroll
         for (int i = 0; i < NS; i++) { x0[i] = xr[i]; m[i] = meas[(size_t)b * NS + i]; }
         state_to_delta(d, x0, m);
@@ -727,14 +733,14 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
         for (int i = 0; i < NX; i++) { I.zLow[s0 * NZ + i] = d[i]; I.zUpp[s0 * NZ + i] = d[i]; }
 #pragma unroll
         for (int i = 0; i < NU; i++) {
-            const double ur = I.uref[s0 * NU + i];
+            const real_t ur = I.uref[s0 * NU + i];
             I.zLow[s0 * NZ + NX + i] = v.lb[i] - ur;
             I.zUpp[s0 * NZ + NX + i] = v.ub[i] - ur;
         }
     }
     __syncthreads();
 
-    const double obj = stage_pass<kBegin>(v, I, 1, L);
+    const real_t obj = stage_pass<kBegin>(v, I, 1, L);
     const int last = publish_changes<true>(v, I, L);
     if (tid == 0) {
         I.sc->objInc = obj;
@@ -751,37 +757,38 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
 
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int nextIt) {
-    extern __shared__ double lds_raw[];
+    extern __shared__ real_t lds_raw[];
     const StageLds L = carve_step(lds_raw, v.N);
     const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
     if (I.sc->status != ST_RUNNING) return;
     const int N = v.N, n = NX * N;
     const bool regularized = I.sc->regularized != 0;
-    double objInc = I.sc->objInc;
+    real_t objInc = I.sc->objInc;
 
     for (int s = tid; s <= N; s += kStageThreads) L.chg[s] = 0;
 
-    double alphaMinAS, fullStepSlope, fullStepNorm2;
+    real_t alphaMinAS, fullStepSlope, fullStepNorm2;
     const bool keepGrad = nextIt <= kMaxIter;   // the last iteration leaves the gradient record alone
     const bool haveSlope = L.terms != nullptr;
     // z and y hold the value trial at step length zAlpha, whose objective is objKept
-    double objKept = directions_and_full_step_trial(v, I, L, keepGrad, &alphaMinAS, &fullStepSlope,
+    real_t objKept = directions_and_full_step_trial(v, I, L, keepGrad, &alphaMinAS, &fullStepSlope,
                                                     &fullStepNorm2);
-    double zAlpha = 1.;
+    real_t zAlpha = 1.;
     // step length whose gradient grad holds, if any
-    double gradAlpha = (haveSlope && keepGrad) ? 1. : __builtin_nan("");
+    real_t gradAlpha = (haveSlope && keepGrad) ? 1. : __builtin_nan("");
     bool gradFromSweep = haveSlope && keepGrad;     // false once a slope trial rewrites grad
 
-    double alpha;
+    real_t alpha;
     int lsIter = 0;
     if (alphaMinAS > 1. - kEqTol && !regularized) {
         alpha = 1.;
     } else {
         // backtracking on the dual objective (dual_qp.c:1294-1334)
-        double alphaMax = 1.;
-        const double minProg = kLsMinRel * fabs(objInc) + kLsMinAbs;
-        const double nd = sqrt(I.sc->dlNorm2);
+        real_t alphaMax = 1.;
+        // fabs is double-valued in the reference, which makes the whole expression double
+        const real_t minProg = (real_t)((double)kLsMinRel * fabs((double)objInc) + (double)kLsMinAbs);
+        const real_t nd = sqrt(I.sc->dlNorm2);
         alpha = alphaMax;
         int st = ST_LS_MAXITER;
         for (; lsIter < kMaxLsIter; ++lsIter) {
@@ -791,7 +798,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
             }
             if (objKept > objInc + minProg) { st = ST_OK; break; }
             alpha = alpha * kLsReduction;
-            if (nd * (alpha - 0.) < kEqTol) { alpha = 0.; st = ST_LS_MIN_STEP; break; }
+            if (nd * (alpha - (real_t)0.) < kEqTol) { alpha = 0.; st = ST_LS_MIN_STEP; break; }
         }
         if (st == ST_LS_MIN_STEP) {
             if (tid == 0) {
@@ -802,14 +809,14 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
             return;
         }
         {
-            const double cand = alpha / kLsReduction;
+            const real_t cand = alpha / kLsReduction;
             alphaMax = (alphaMax < cand) ? alphaMax : cand;
         }
         // gradient bisection (dual_qp.c:1341-1470).  Nearly every search ends with
         // its first trial; the few that go on are handed to k_line_search_tail,
         // which evaluates them faster than this kernel's resources allow.  A trial
         // at the step length z already holds needs no new trial point.
-        auto slope_at = [&](double at) {
+        auto slope_at = [&](real_t at) {
             if (haveSlope && at == 1.) return fullStepSlope;    // the first sweep made it
             if (at == zAlpha) {
                 // the gradient at z is what the next Newton set-up starts from if this
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
                 const bool keep = nextIt <= kMaxIter;
                 if (keep) { gradAlpha = at; gradFromSweep = false; }
                 return block_ordered_sum(n, L, [&](int r) {
-                    const double g = gradient_row(v, I, I.z, r);
+                    const real_t g = gradient_row(v, I, I.z, r);
                     if (keep) I.grad[r] = g;
                     return g * I.dl[r];
                 });
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
                 return gradient_row(v, I, I.tmp, r) * I.dl[r];
             });
         };
-        const double normal = (1. < nd) ? 1. : nd;
+        const real_t normal = (1. < nd) ? 1. : nd;
         Bisection bs{alphaMinAS, alphaMax, 1.0, 0., lsIter, 0, false};
         settle(bs);
         const bool handOver = tail_capable(v);
@@ -872,16 +879,16 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 // many run side by side, settles kTailDepth levels.  Leaves the step length
 // and trial count in the instance's scalars for k_line_search_commit.
 __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, int nextIt) {
-    extern __shared__ double lds_raw[];
+    extern __shared__ real_t lds_raw[];
     const int tid = threadIdx.x;
     const int N = v.N, n = NX * N, eEnd = NZ * N + NX, E = NZ * (N + 1);
-    double* tp = lds_raw;                                   // [points][E] clipped trial points
-    double* terms = lds_raw + kTailPoints * E;              // [points][stride >= n] slope terms
+    real_t* tp = lds_raw;                                   // [points][E] clipped trial points
+    real_t* terms = lds_raw + kTailPoints * E;              // [points][stride >= n] slope terms
     const int ts = tail_term_stride(n);
-    double* slopes = terms + kTailPoints * ts;              // [points]
-    double* plan = slopes + 8;                              // [0] search over, [1..points] trial steps
-    double* mags = plan + 8;                                // [points] sums of the terms' magnitudes
-    double* redo = mags + 8;                                // [0] != 0: this round needs the row-order sums
+    real_t* slopes = terms + kTailPoints * ts;              // [points]
+    real_t* plan = slopes + 8;                              // [0] search over, [1..points] trial steps
+    real_t* mags = plan + 8;                                // [points] sums of the terms' magnitudes
+    real_t* redo = mags + 8;                                // [0] != 0: this round needs the row-order sums
     // gradient rows: thread t < 6 N owns rows h and h + 6 of block t / 6
     const int rk = tid / (NX / 2), rh = tid % (NX / 2);
     const bool rowOn = rk < N;
@@ -890,9 +897,9 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
         const int b = v.tailList[item];
         Inst I = instance(v, b);
         Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
-        const double normal = I.sc->lsNormal;
+        const real_t normal = I.sc->lsNormal;
 
-        double zu[kTailElems], dzv[kTailElems], lo[kTailElems], up[kTailElems];
+        real_t zu[kTailElems], dzv[kTailElems], lo[kTailElems], up[kTailElems];
 #pragma unroll
         for (int m = 0; m < kTailElems; m++) {
             const int e = tid + m * kTailThreads;
@@ -903,12 +910,12 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
             up[m] = in ? I.zUpp[e] : 0.;
         }
         // this thread's two Jacobian rows, residuals and multiplier-step entries
-        double ca[NZ], cb[NZ], resA = 0., resB = 0., dlA = 0., dlB = 0.;
+        real_t ca[NZ], cb[NZ], resA = 0., resB = 0., dlA = 0., dlB = 0.;
 #pragma unroll
         for (int j = 0; j < NZ; j++) { ca[j] = 0.; cb[j] = 0.; }
         if (rowOn) {
             const int s = stage_slot(v, rk);
-            const double* blk = I.C + (size_t)s * (NX * NZ);
+            const real_t* blk = I.C + (size_t)s * (NX * NZ);
             load_row15(blk + rh * NZ, ca);
             load_row15(blk + (rh + NX / 2) * NZ, cb);
             resA = I.c[s * NX + rh];
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
         // Trial steps in heap order: node 1 is the next trial, nodes 2i and 2i+1
         // the trials after node i when its slope is negative / positive.
         auto plan_round = [&]() {
-            double at[kTailPoints + 1];
+            real_t at[kTailPoints + 1];
             Bisection st[kTailPoints + 1];
             st[1] = bs;
 #pragma unroll
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
         if (tid < kWave) plan_round();
         __syncthreads();
         while (plan[0] == 0.) {
-            double at[kTailPoints + 1];
+            real_t at[kTailPoints + 1];
 #pragma unroll
             for (int i = 1; i <= kTailPoints; i++) at[i] = plan[i];
 #pragma unroll
@@ -955,7 +962,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
                 if (e < eEnd) {
 #pragma unroll
                     for (int p = 0; p < kTailPoints; p++) {
-                        double y0, y1;
+                        real_t y0, y1;
                         tp[p * E + e] = clip_gap(zu[m] + at[p + 1] * dzv[m], lo[m], up[m], &y0, &y1);
                     }
                 }
@@ -965,11 +972,11 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
                 const int s = stage_slot(v, rk), sn = stage_slot(v, rk + 1);
 #pragma unroll 1
                 for (int p = 0; p < kTailPoints; p++) {
-                    const double* zk = tp + p * E + s * NZ;
-                    double a = 0., b2 = 0.;
+                    const real_t* zk = tp + p * E + s * NZ;
+                    real_t a = 0., b2 = 0.;
 #pragma unroll
                     for (int j = 0; j < NZ; j++) {
-                        const double zj = zk[j];
+                        const real_t zj = zk[j];
                         a += ca[j] * zj;
                         b2 += cb[j] * zj;
                     }
@@ -990,10 +997,10 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
                 const int w = tid >> 6, lane = tid & 63, p = w & 7;
                 if (p < kTailPoints) {
                     const bool magnitude = w >= 8;
-                    const double* tv = terms + p * ts;
-                    double acc = 0.;
+                    const real_t* tv = terms + p * ts;
+                    real_t acc = 0.;
                     for (int r = lane; r < n; r += kWave) {
-                        const double x = tv[r];
+                        const real_t x = tv[r];
                         acc += magnitude ? fabs(x) : x;
                     }
 #pragma unroll
@@ -1028,7 +1035,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
             if (redo[0] != 0.) {
                 if (tid < 8 * 16) {     // one DPP row per trial point (the eighth row idles along)
                     const int p = (tid >> 4) < kTailPoints ? (tid >> 4) : kTailPoints - 1;
-                    const double sv = accumulate_by_row(0., terms + p * ts, n);
+                    const real_t sv = accumulate_by_row(0., terms + p * ts, n);
                     if ((tid & 15) == 0 && (tid >> 4) < kTailPoints) slopes[p] = sv;
                 }
                 __syncthreads();
@@ -1037,7 +1044,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
 #pragma unroll
                     for (int level = 0; level < kTailDepth; level++) {
                         if (!bs.done) {
-                            const double sv = slopes[node - 1];
+                            const real_t sv = slopes[node - 1];
                             const bool neg = bs.phase == 0 ? (sv / normal < 0.) : !(sv > 0);
                             advance(bs, sv, normal);
                             node = 2 * node + (neg ? 0 : 1);
@@ -1059,13 +1066,13 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
 
 // Commit and next Newton set-up of the instances k_line_search_tail finished.
 __global__ __launch_bounds__(kStageThreads) void k_line_search_commit(BatchView v, int nextIt) {
-    extern __shared__ double lds_raw[];
+    extern __shared__ real_t lds_raw[];
     const StageLds L = carve(lds_raw, v.N);
     const int tid = threadIdx.x;
     const int count = v.tailCount[nextIt - 2];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         Inst I = instance(v, v.tailList[item]);
-        const double alpha = I.sc->alpha;
+        const real_t alpha = I.sc->alpha;
         const int lsIter = I.sc->lsIter;
         for (int s = tid; s <= v.N; s += kStageThreads) L.chg[s] = 0;
         __syncthreads();
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(kStageThreads) void k_line_search_commit(BatchView 
 // Newton Hessian block rows of the same instances, sixteen wavefronts each: a
 // lone instance's block rows are a latency chain per wavefront.
 __global__ __launch_bounds__(kTailThreads) void k_line_search_hessian(BatchView v, int nextIt) {
-    extern __shared__ double lds_raw[];
+    extern __shared__ real_t lds_raw[];
     const int count = v.tailCount[nextIt - 2];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         Inst I = instance(v, v.tailList[item]);
@@ -1086,7 +1093,7 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_hessian(BatchView 
     }
 }
 
-void launch_qp_begin(const BatchView& v, const double* meas, hipStream_t s) {
+void launch_qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
     hipLaunchKernelGGL(k_qp_begin, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
 }
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
@@ -1110,7 +1117,7 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
                        stage_lds_bytes(v.N), s, v, next_it);
     if (next_it <= kMaxIter)
         hipLaunchKernelGGL(k_line_search_hessian, dim3(grid_hessian), dim3(kTailThreads),
-                           (kTailThreads / kWave) * 2 * NX * NZ * sizeof(double), s, v, next_it);
+                           (kTailThreads / kWave) * 2 * NX * NZ * sizeof(real_t), s, v, next_it);
 }
 
 }  // namespace nmpc

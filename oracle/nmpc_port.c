@@ -879,8 +879,8 @@ void port_state_plus_delta(real_t *out, const real_t *x, const real_t *d) {
     }
     real_t pp = d[6] * d[6] + d[7] * d[7] + d[8] * d[8];
     real_t dq[4];
-    dq[3] = (16.0 - pp) / (16.0 + pp);
-    real_t sc = 0.25 * (1.0 + dq[3]);
+    dq[3] = ((real_t)16.0 - pp) / ((real_t)16.0 + pp);
+    real_t sc = (real_t)0.25 * ((real_t)1.0 + dq[3]);
     dq[0] = sc * d[6]; dq[1] = sc * d[7]; dq[2] = sc * d[8];
     quat_mul(&out[6], dq, &x[6]);
 }

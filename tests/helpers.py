@@ -75,8 +75,9 @@ def drive_gpu_batch(gs, dump=False):
     bt.initialise_horizon()
     bt.set_wind_velocity(np.stack([g["winds"][0] for g in gs]))
     bt.set_reference(np.stack([g["refs"][:N + 1] for g in gs]))
-    out = dict(u=np.zeros((B, steps, 3)), status=np.zeros((B, steps), np.int32),
-               iters=np.zeros((B, steps), np.int32), z0=np.zeros((B, steps, 15)))
+    dt = bt.dtype
+    out = dict(u=np.zeros((B, steps, 3), dt), status=np.zeros((B, steps), np.int32),
+               iters=np.zeros((B, steps), np.int32), z0=np.zeros((B, steps, 15), dt))
     if dump:
         out["loaded_Cc"] = [bt.stages(b)[:, :192].copy() for b in range(B)]
     for k in range(steps):
@@ -86,10 +87,8 @@ def drive_gpu_batch(gs, dump=False):
         u, st, it = bt.get_controls()
         out["u"][:, k], out["status"][:, k], out["iters"][:, k] = u, st, it
         for b in range(B):
-            rec = np.zeros(332)
-            bt._ck(bt.lib.nmpc_batch_get_stage(
-                bt.h, b, 0, rec.ctypes.data_as(__import__("ctypes").POINTER(
-                    __import__("ctypes").c_double))))
+            rec = np.zeros(332, dt)
+            bt._ck(bt.lib.nmpc_batch_get_stage(bt.h, b, 0, rec.ctypes.data_as(bt.lib.preal)))
             out["z0"][b, k] = rec[238:253]
         bt.update_horizon(np.stack([g["refs"][N + 1 + k] for g in gs]))
     if dump:

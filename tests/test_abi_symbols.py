@@ -61,6 +61,23 @@ def test_compiled_configuration():
     assert ctypes.sizeof(_lib.State) == 13 * 8
 
 
+def test_single_precision_library_exports_and_configuration():
+    """libcnmpc_f32.so: the same entry points with real_t = float, the
+    reference's shipped configuration (include/config.h:27)."""
+    from nmpc_amd import _lib
+    path = os.path.join(ROOT, "nmpc_amd", "libcnmpc_f32.so")
+    assert os.path.exists(path), "build with `make -C nmpc_amd/csrc`"
+    raw = ctypes.CDLL(path)
+    for name in declared_functions():
+        assert hasattr(raw, name), "missing export: " + name
+    lib = _lib.load(path)
+    assert lib.nmpc_config_get_precision() == 0     # NMPC_PRECISION_FLOAT
+    assert lib.real is ctypes.c_float and lib.np_real == "float32"
+    assert ctypes.sizeof(lib.State) == 13 * 4
+    assert lib.nmpc_config_get_step_length() == 1.0 / 50.0 or \
+        lib.nmpc_config_get_step_length() == float(__import__("numpy").float32(1.0 / 50.0))
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from nmpc_amd import _lib
     with pytest.raises(_lib.NmpcError):
