@@ -257,6 +257,10 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
                       void* stream) {
     if (!out || instances == 0 || horizon < 2)
         return fail(NMPC_E_ARG, "nmpc_batch_create: need out != NULL, instances >= 1, horizon >= 2");
+    // the kernels index (instance, stage) pairs with 32-bit integers
+    if ((uint64_t)instances * ((uint64_t)horizon + 1) >= (1ull << 31))
+        return fail(NMPC_E_ARG, "nmpc_batch_create: instances x (horizon + 1) = %llu beyond 2^31",
+                    (unsigned long long)instances * (horizon + 1ull));
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev)

@@ -4,7 +4,7 @@
 //   k_store_refs      reference points -> xref / uref rings
 //   k_init_stages     nmpc_init for every instance      (cnmpc.c:872-948)
 //   k_linearise       RK4 + finite-difference stage linearisation, one lane per
-//                     (instance, stage, column), fused with the stage-QP
+//                     (instance, stage, integrated column), fused with the stage-QP
 //                     re-staging                         (cnmpc.c:583-667, 1022-1080;
 //                                                        qpDUNES/setup_qp.c:547-585)
 //   k_linearise_free  the same stage body on caller-supplied samples
@@ -23,11 +23,8 @@
 #include "qp_common.hpp"
 
 // Minimum resident wavefronts per SIMD the stage linearisation is compiled for.
-// The stateless kernel fits three (165 registers).  The batch kernel also holds
-// the values its re-staging needs across the integration (178 registers): held
-// to three it spills them and is 9 % slower than at two.
 #ifndef NMPC_LINEARISE_WAVES
-#define NMPC_LINEARISE_WAVES 2
+#define NMPC_LINEARISE_WAVES 3
 #endif
 #ifndef NMPC_LINEARISE_FREE_WAVES
 #define NMPC_LINEARISE_FREE_WAVES 3
@@ -145,188 +142,296 @@ __global__ void k_init_stages(BatchView v, int part) {
 }
 
 // ------------------------------------------------------------------------
-// Stage linearisation.  Lane j of each 16-lane group integrates the reference
-// point perturbed along column j (j == 15: unperturbed).  The nominal end state
-// is broadcast inside the group; lane j < 15 then owns column j of the 12x15
-// Jacobian, lane 15 owns the residual.
+// Stage linearisation.  Thirteen lanes per stage: lane 0 of a group integrates
+// the unperturbed point, lane c > 0 the point perturbed along column c + 2 of
+// the 12x15 Jacobian (velocity, attitude, body rates, controls).  The three
+// position columns take no integration of their own: the model never reads the
+// position, so their end state is the nominal one with one position entry
+// re-added from the nominal lane's Runge-Kutta sums, and their Jacobian entries
+// follow from the nominal lane alone (the differences of equal entries are
+// evaluated, not assumed zero, so that non-finite states propagate as they do
+// in the reference).
 //
-// The kernel is bound by instruction issue, not by memory, so it is written to
-// keep registers low enough for three wavefronts per SIMD: lane i < 13 of a
-// group fetches entry i of the stage's state and of the next state (one
-// register pair each instead of 26 per lane; the 13 entries are one contiguous
-// 104-byte read per group), every lane collects the state through DPP row
-// broadcasts, and the next state is only unpacked once the integration is over.
-using Seq12 = std::make_integer_sequence<int, NX>;
-template <int... I>
-NMPC_DEV void gather_row(real_t (&out)[NS], real_t mine, std::integer_sequence<int, I...>) {
-    ((out[I] = row_bcast<I>(mine)), ...);
-}
-template <int... I>
-NMPC_DEV void bcast_from_last(real_t (&out)[NS], const real_t (&in)[NS],
-                              std::integer_sequence<int, I...>) {
-    ((out[I] = row_bcast<15>(in[I])), ...);
-}
+// A 256-lane workgroup holds 19 stages (247 lanes).  The groups do not line up
+// with wavefronts or DPP rows, so states travel through LDS: 13 lanes fetch the
+// 13 entries of the stage's state (one contiguous 104-byte read), every lane
+// reads them back; the nominal end state comes the same way.  Jacobian and
+// residual are assembled in an LDS tile and leave in 16-byte row-contiguous
+// stores.  The kernel is bound by instruction issue, not memory; everything
+// that is only needed after the integration (multipliers, Hessian, bounds)
+// waits in LDS rather than in registers, which keeps three wavefronts per SIMD.
+constexpr int kLanesPerStage = 13;
+constexpr int kStagesPerBlock = 19;
+constexpr int kTileRow = NX * NZ + NX;      // 180 Jacobian entries (row-major 12x15), 12 residuals
+constexpr int kPerVec = 16 / (int)sizeof(real_t);
+typedef real_t Vec16 __attribute__((ext_vector_type(kPerVec)));
 
-// zdev: null, or the stage variable z (15 entries) the expansion point is moved
-// by: x (+) z[0:12], u + z[12:15]; this lane's entry of it comes back in *zj.
-template <int... I>
-NMPC_DEV void gather_row15(real_t (&out)[NZ], real_t mine, std::integer_sequence<int, I...>) {
-    ((out[I] = row_bcast<I>(mine)), ...);
-}
+struct LineariseLds {
+    alignas(16) real_t tile[kStagesPerBlock][kTileRow];
+    real_t x[kStagesPerBlock][NS];          // expansion point (reference state)
+    real_t next[kStagesPerBlock][NS];       // reference state of the next stage
+    real_t moved[kStagesPerBlock][NS];      // nominal end state
+    real_t u[kStagesPerBlock][NU];          // reference control
+    real_t wind[kStagesPerBlock][3];
+    // batch kernel only
+    real_t lam[kStagesPerBlock][NX];        // multipliers of the coupling to stage k + 1
+    real_t lam_prev[kStagesPerBlock][NX];   // ... to stage k - 1
+    real_t z[kStagesPerBlock][NZ];          // stage solution (real-time iteration)
+    real_t H[NZ], lb[NU], ub[NU];
+    int row[kStagesPerBlock];               // (instance, slot) row of the stage in C and c
+    int inst[kStagesPerBlock], pos[kStagesPerBlock], slot[kStagesPerBlock];
+};
 
-NMPC_DEV void linearise_lane(const real_t* xr, const real_t* xq, const real_t* ur,
-                             const real_t* wr, const real_t* lower, const real_t* upper,
-                             int j, real_t* out12, const real_t* zdev = nullptr,
-                             real_t* zj = nullptr) {
-    using Seq13 = std::make_integer_sequence<int, NS>;
-    const int li = j < NS ? j : 0;
-    const real_t mine = xr[li], mine_next = xq[li];
-    real_t x[NS], u[NU], wind[3], moved[NS], base[NS], next[NS];
-    gather_row(x, mine, Seq13{});
+// Lanes of one group, after L.x[g], L.next[g], L.u[g], L.wind[g] (and L.z[g])
+// are in place: leaves
+// this lane's column (c > 0, scaled by 1 / h) or the residual (c == 0) in col
+// and in the tile; the nominal lane also writes the position columns.  The
+// caller synchronises before the tile is read.
+// MOVE: the expansion point is moved by the stage solution, x (+) z[0:12],
+// u + z[12:15].
+template <bool MOVE>
+NMPC_DEV void linearise_lanes(LineariseLds& L, bool active, int g, int c, const real_t* lower,
+                              const real_t* upper, real_t (&col)[NX]) {
+    const int j = c == 0 ? 15 : c + 2;
+    real_t moved[NS];
+    real_t hinv = (real_t)0.0;
+    if (active) {
+        real_t x[NS], u[NU], wind[3], ta[3], tb[3];
 #pragma unroll
-    for (int i = 0; i < NU; i++) { u[i] = ur[i]; wind[i] = wr[i]; }
-    if (zdev) {
-        const real_t zmine = zdev[j < NZ ? j : 0];
-        real_t z[NZ], x0[NS];
-        gather_row15(z, zmine, std::make_integer_sequence<int, NZ>{});
+        for (int i = 0; i < NS; i++) x[i] = L.x[g][i];
 #pragma unroll
-        for (int i = 0; i < NS; i++) x0[i] = x[i];
-        state_plus_delta(x, x0, z);
+        for (int i = 0; i < NU; i++) { u[i] = L.u[g][i]; wind[i] = L.wind[g][i]; }
+        if (MOVE) {
+            real_t z[NZ], x0[NS];
 #pragma unroll
-        for (int i = 0; i < NU; i++) u[i] = u[i] + z[NX + i];
-        *zj = zmine;
+            for (int i = 0; i < NZ; i++) z[i] = L.z[g][i];
+#pragma unroll
+            for (int i = 0; i < NS; i++) x0[i] = x[i];
+            state_plus_delta(x, x0, z);
+#pragma unroll
+            for (int i = 0; i < NU; i++) u[i] = u[i] + z[NX + i];
+        }
+        const real_t p0[3] = {x[0], x[1], x[2]};
+        __builtin_assume(j >= 3);                   // no lane integrates a position column
+        hinv = perturb_point(x, u, j, lower, upper);
+        rk4_step(moved, x, u, wind, kStepLength, ta, tb);
+        if (c == 0) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) L.moved[g][i] = moved[i];
+            // Columns 0..2 (cnmpc.c:600-606 with the perturbed entry carried
+            // through the last line of the integrator, cnmpc.c:393-397).
+            real_t diag[3], same[NX];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const real_t pm = ((p0[i] + kFdStep) + ta[i]) + tb[i];
+                diag[i] = (pm - moved[i]) * hinv;
+                same[i] = (moved[i] - moved[i]) * hinv;
+                same[3 + i] = (moved[3 + i] - moved[3 + i]) * hinv;
+                same[9 + i] = (moved[10 + i] - moved[10 + i]) * hinv;
+            }
+            real_t cj[4], e[4];
+            cj[0] = moved[6]; cj[1] = moved[7]; cj[2] = moved[8]; cj[3] = -moved[9];
+            quat_mul(e, &moved[6], cj);
+            if (e[3] < 0) { e[0] = -e[0]; e[1] = -e[1]; e[2] = -e[2]; e[3] = -e[3]; }
+            const real_t d = (real_t)4.0 / ((real_t)1.0 + e[3]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) same[6 + i] = (e[i] * d) * hinv;
+#pragma unroll
+            for (int r = 0; r < NX; r++)
+#pragma unroll
+                for (int jp = 0; jp < 3; jp++) L.tile[g][r * NZ + jp] = (r == jp) ? diag[jp] : same[r];
+        }
     }
-    const real_t hinv = perturb_point(x, u, j, lower, upper);
-    rk4_step(moved, x, u, wind, kStepLength);
-    bcast_from_last(base, moved, Seq13{});              // nominal end state
-    gather_row(next, mine_next, Seq13{});               // (every lane of the row takes part)
+    __syncthreads();
+    if (active) {
+        const real_t* bp = c == 0 ? L.next[g] : L.moved[g];
+        real_t base[NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) base[i] = (j == 15) ? next[i] : base[i];
-    state_to_delta(out12, base, moved);
-    if (j < 15) {
+        for (int i = 0; i < NS; i++) base[i] = bp[i];
+        state_to_delta(col, base, moved);
+        if (c > 0) {
+            real_t* t = &L.tile[g][j];
 #pragma unroll
-        for (int r = 0; r < NX; r++) out12[r] = out12[r] * hinv;
+            for (int r = 0; r < NX; r++) { col[r] = col[r] * hinv; t[r * NZ] = col[r]; }
+        } else {
+            real_t* t = &L.tile[g][NX * NZ];
+#pragma unroll
+            for (int r = 0; r < NX; r++) t[r] = col[r];
+        }
     }
 }
 
-template <int... I>
-NMPC_DEV real_t dot_with_row(const real_t (&col)[NX], real_t mine, std::integer_sequence<int, I...>) {
-    real_t acc = 0.;
-    ((acc += col[I] * row_bcast<I>(mine)), ...);
-    return acc;
+// Jacobian rows and residual of the workgroup's stages from the tile to global
+// memory; stage gg goes to row row_of(gg) of jac ([.][180]) and res ([.][12]).
+template <bool WIDE, typename RowOf>
+NMPC_DEV void store_tiles(const LineariseLds& L, int nvalid, real_t* jac, real_t* res, RowOf row_of) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    for (int gg = wave; gg < nvalid; gg += 4) {
+        const long row = row_of(gg);                // the same for the whole wavefront
+        real_t* jr = jac + row * (NX * NZ);
+        real_t* rr = res + row * NX;
+        const real_t* tl = L.tile[gg];
+        if (WIDE) {
+            constexpr int chunks = kTileRow / kPerVec, jchunks = NX * NZ / kPerVec;
+#pragma unroll
+            for (int i = 0; i < (chunks + 63) / 64; i++) {
+                const int e = i * 64 + lane;
+                if (e < chunks) {
+                    real_t* dst = e < jchunks ? jr + e * kPerVec : rr + (e - jchunks) * kPerVec;
+                    *reinterpret_cast<Vec16*>(dst) = *reinterpret_cast<const Vec16*>(tl + e * kPerVec);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kTileRow / 64; i++) {
+                const int e = i * 64 + lane;
+                real_t* dst = e < NX * NZ ? jr + e : rr + (e - NX * NZ);
+                *dst = tl[e];
+            }
+        }
+    }
 }
 
-// The multipliers, bounds and Hessian entry the re-staging needs are fetched
-// before the integration, one value per lane (a wavefront that asked for them
-// afterwards would sit out the memory latency with nothing left to do), and
-// the multiplier block is shared out by row broadcasts at the end.
+// The stage-QP re-staging is fused in (qpDUNES/setup_qp.c:547-585,
+// stage_qp_solver_clipping.c:42-98): qStep := C' lambda_{k+1} - lambda_k + g,
+// pStep := c . lambda_{k+1}, dz := -(qStep / H), zUnc := 0, q := 0, bounds.
 // ABOUT_SOLUTION: the expansion point of every stage is moved by the stage's
 // current solution z and the residual is taken back by C z, so that the stage
 // stays a deviation from the reference: c = delta(x_ref[k+1], f(x, u)) - C z
 // (the real-time-iteration preparation step; the reference has no code for it).
-template <int... J>
-NMPC_DEV real_t sum_over_columns(real_t mine, std::integer_sequence<int, J...>) {
-    real_t acc = 0.;
-    ((acc += row_bcast<J>(mine)), ...);
-    return acc;
-}
-
 template <bool ABOUT_SOLUTION>
 __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchView v, int first, int count) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = (int)(gid & 15);
-    long st = gid >> 4;
+    __shared__ LineariseLds L;
+    const int t = threadIdx.x, g = t / kLanesPerStage, c = t - g * kLanesPerStage;
     const long total = (long)v.B * count;
-    const bool live = st < total;
-    if (!live) st = total - 1;              // keep the whole group in the broadcasts
-    const int b = (int)(st / count), k = first + (int)(st % count);
-    const int s = stage_slot(v, k);
-    const real_t* ur = v.uref + ((size_t)b * v.N + s) * NU;
-    // multipliers of the two coupling constraints this stage takes part in
-    const real_t* lam = v.lam + (size_t)b * v.N * NX;
-    const real_t lam_next = lam[(size_t)lam_slot(v, k) * NX + (j < NX ? j : 0)];
-    const bool has_prev = k > 0 && j < NX;
-    const real_t lam_prev = has_prev ? lam[(size_t)lam_slot(v, k - 1) * NX + j] : 0.;
-    real_t hj = v.H[0], lo = -kInfty, up = kInfty;
+    const long st = (long)blockIdx.x * kStagesPerBlock + g;
+    const bool active = g < kStagesPerBlock && st < total;
+    if (t == 0) {                   // kernel arguments: static indices only
 #pragma unroll
-    for (int i = 1; i < NZ; i++) hj = (i == j) ? v.H[i] : hj;
-    if (j >= NX && j < NZ) {
-        const real_t uj = ur[j - NX];
-        real_t lbj = 0.0, ubj = 0.0;
+        for (int i = 0; i < NZ; i++) L.H[i] = v.H[i];
 #pragma unroll
-        for (int i = 0; i < NU; i++) {
-            lbj = (i == j - NX) ? v.lb[i] : lbj;
-            ubj = (i == j - NX) ? v.ub[i] : ubj;
-        }
-        lo = lbj - uj;
-        up = ubj - uj;
+        for (int i = 0; i < NU; i++) { L.lb[i] = v.lb[i]; L.ub[i] = v.ub[i]; }
     }
-    real_t col[NX];
-    {
+    if (active) {
+        // (the launcher keeps B * count below 2^31: 32-bit division)
+        const unsigned sq = (unsigned)st / (unsigned)count;
+        const int b = (int)sq, k = first + (int)((unsigned)st - sq * (unsigned)count);
+        const int s = stage_slot(v, k);
+        // every load is issued before the first one is waited for
         const real_t* xref = v.xref + (size_t)b * (v.N + 1) * NS;
-        real_t zj = 0.;
-        const real_t* zdev = ABOUT_SOLUTION ? v.z + ((size_t)b * (v.N + 1) + s) * NZ : nullptr;
-        linearise_lane(xref + (size_t)xref_slot(v, k) * NS, xref + (size_t)xref_slot(v, k + 1) * NS,
-                       ur, v.wind + (size_t)b * 3, v.lb, v.ub, j, col, zdev, &zj);
+        const real_t* lam = v.lam + (size_t)b * v.N * NX;   // multipliers of the two couplings of the stage
+        const int cl = c < NX ? c : 0, cu = c < NU + 3 ? c : 0;
+        const real_t xv = xref[(size_t)xref_slot(v, k) * NS + c];
+        const real_t nv = xref[(size_t)xref_slot(v, k + 1) * NS + c];
+        const real_t lv = lam[(size_t)lam_slot(v, k) * NX + cl];
+        const real_t pv = lam[(size_t)lam_slot(v, k > 0 ? k - 1 : 0) * NX + cl];
+        const real_t uw = cu < NU ? v.uref[((size_t)b * v.N + s) * NU + cu] : v.wind[(size_t)b * 3 + (cu - NU)];
+        real_t zv = 0., zw = 0.;
         if (ABOUT_SOLUTION) {
-            // row r of C z: the columns' products added in column order; lane 15 keeps them
-#pragma unroll
-            for (int r = 0; r < NX; r++) {
-                const real_t prod = (j < NZ) ? col[r] * zj : 0.;
-                const real_t cz = sum_over_columns(prod, std::make_integer_sequence<int, NZ>{});
-                if (j == 15) col[r] = col[r] - cz;
-            }
+            const real_t* zp = v.z + ((size_t)b * (v.N + 1) + s) * NZ;
+            zv = zp[c];
+            zw = zp[c < NZ - kLanesPerStage ? kLanesPerStage + c : 0];
         }
+        L.x[g][c] = xv;
+        L.next[g][c] = nv;
+        if (c < NX) { L.lam[g][c] = lv; L.lam_prev[g][c] = k > 0 ? pv : (real_t)0.0; }
+        if (c < NU) L.u[g][c] = uw;
+        else if (c < NU + 3) L.wind[g][c - NU] = uw;
+        if (ABOUT_SOLUTION) {
+            L.z[g][c] = zv;
+            if (c < NZ - kLanesPerStage) L.z[g][kLanesPerStage + c] = zw;
+        }
+        if (c == 0) { L.row[g] = b * v.N + s; L.inst[g] = b; L.pos[g] = k; L.slot[g] = s; }
     }
-    // C' lambda_{k+1} (lanes j < 15) and c . lambda_{k+1} (lane 15): the same sum
-    const real_t dot = dot_with_row(col, lam_next, Seq12{});
-    if (!live) return;
-
-    const size_t sb = (size_t)b, N = (size_t)v.N, N1 = N + 1;
-    if (j < 15) {
-        real_t* Ck = v.C + (sb * N + s) * (NX * NZ);
+    __syncthreads();
+    real_t col[NX];
+    linearise_lanes<ABOUT_SOLUTION>(L, active, g, c, v.lb, v.ub, col);
+    real_t dot_own = 0.;                            // own column of C . lambda_{k+1}
+    if (active && c > 0) {
 #pragma unroll
-        for (int r = 0; r < NX; r++) Ck[r * NZ + j] = col[r];
+        for (int r = 0; r < NX; r++) dot_own += col[r] * L.lam[g][r];
+    }
+    __syncthreads();                                // the tile is complete
+    if (ABOUT_SOLUTION) {
+        if (active && c > 0) {                      // row c - 1 of C z, the columns in order
+            const int r = c - 1;
+            real_t cz = 0.;
+#pragma unroll
+            for (int jj = 0; jj < NZ; jj++) cz += L.tile[g][r * NZ + jj] * L.z[g][jj];
+            L.tile[g][NX * NZ + r] = L.tile[g][NX * NZ + r] - cz;
+        }
+        __syncthreads();
+    }
+    // Global stores only from here on: a workgroup barrier behind a store waits
+    // for the store to complete.  (Instance, position and slot come back from
+    // LDS rather than staying in registers across the integration.)
+    const int gs = active ? g : 0;
+    const int b = L.inst[gs], k = L.pos[gs], s = L.slot[gs];
+    const size_t zrow = ((size_t)b * (v.N + 1) + s) * NZ;
+    auto restage = [&](int jv, real_t dot) {        // stage variable jv, dot = column jv of C . lambda_{k+1}
         real_t qs = dot;
-        if (has_prev) qs -= lam_prev;
+        if (k > 0 && jv < NX) qs -= L.lam_prev[g][jv];
         qs = qs + 0.0;
-        const real_t d = qs / hj;
-        const size_t e = (sb * N1 + s) * NZ + j;
+        const real_t d = qs / L.H[jv];
+        real_t lo = -kInfty, up = kInfty;
+        if (jv >= NX) {
+            const real_t uj = L.u[g][jv - NX];
+            lo = L.lb[jv - NX] - uj;
+            up = L.ub[jv - NX] - uj;
+        }
+        const size_t e = zrow + jv;
         v.qStep[e] = qs;
         v.dz[e] = -d;
         v.zUnc[e] = 0.0;
         v.q[e] = 0.0;
         v.zLow[e] = lo;
         v.zUpp[e] = up;
-    } else {
-        real_t* cs = v.c + (sb * N + s) * NX;
+    };
+    if (active && c > 0) restage(c + 2, dot_own);
+    if (active && c < 4) {          // the residual (c == 0) and the position columns against lambda_{k+1}
+        const real_t* src = &L.tile[g][c == 0 ? NX * NZ : c - 1];
+        const int stride = c == 0 ? 1 : NZ;
+        real_t dot = 0.;
 #pragma unroll
-        for (int i = 0; i < NX; i++) cs[i] = col[i];
-        v.pStep[sb * N1 + s] = dot;
+        for (int r = 0; r < NX; r++) dot += src[r * stride] * L.lam[g][r];
+        if (c == 0) v.pStep[(size_t)b * (v.N + 1) + s] = dot;
+        else restage(c - 1, dot);
     }
+    const long left = total - (long)blockIdx.x * kStagesPerBlock;
+    store_tiles<true>(L, left < kStagesPerBlock ? (int)left : kStagesPerBlock, v.C, v.c,
+                      [&](int gg) { return (long)__builtin_amdgcn_readfirstlane(L.row[gg]); });
 }
 
 // Stateless variant: n samples, inputs [n][13] [n][3] [n][13] [n][3],
 // outputs jac [n][180] (row-major 12x15) and res [n][12].
+// WIDE: jac and res are 16-byte aligned.
+template <bool WIDE>
 __global__ __launch_bounds__(256, NMPC_LINEARISE_FREE_WAVES) void k_linearise_free(
     long n, const real_t* __restrict__ xs, const real_t* __restrict__ us,
     const real_t* __restrict__ xnexts, const real_t* __restrict__ winds,
     Bounds bnd, real_t* __restrict__ jac, real_t* __restrict__ res) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = (int)(gid & 15);
-    long st = gid >> 4;
-    const bool live = st < n;
-    if (!live) st = n - 1;
-    real_t col[NX];
-    linearise_lane(xs + st * NS, xnexts + st * NS, us + st * NU, winds + st * 3, bnd.lb, bnd.ub, j, col);
-    if (!live) return;
-    if (j < 15) {
-#pragma unroll
-        for (int r = 0; r < NX; r++) jac[st * (NX * NZ) + r * NZ + j] = col[r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < NX; r++) res[st * NX + r] = col[r];
+    __shared__ LineariseLds L;
+    const int t = threadIdx.x, g = t / kLanesPerStage, c = t - g * kLanesPerStage;
+    const long first = (long)blockIdx.x * kStagesPerBlock;
+    long st = first + g;
+    const bool active = g < kStagesPerBlock && st < n;
+    if (!active) st = 0;
+    if (active) {
+        const int cu = c < NU + 3 ? c : 0;          // (the loads are issued together)
+        const real_t xv = xs[st * NS + c], nv = xnexts[st * NS + c];
+        const real_t uw = cu < NU ? us[st * NU + cu] : winds[st * 3 + (cu - NU)];
+        L.x[g][c] = xv;
+        L.next[g][c] = nv;
+        if (c < NU) L.u[g][c] = uw;
+        else if (c < NU + 3) L.wind[g][c - NU] = uw;
     }
+    __syncthreads();
+    real_t col[NX];
+    linearise_lanes<false>(L, active, g, c, bnd.lb, bnd.ub, col);
+    __syncthreads();
+    const long left = n - first;
+    store_tiles<WIDE>(L, left < kStagesPerBlock ? (int)left : kStagesPerBlock, jac, res,
+                      [&](int gg) { return first + gg; });
 }
 
 __global__ __launch_bounds__(256) void k_rk4_free(long n, const real_t* __restrict__ xs,
@@ -409,17 +514,20 @@ void launch_init_stages(const BatchView& v, int part, hipStream_t s) {
     hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, part);
 }
 void launch_linearise(const BatchView& v, int first, int count, hipStream_t s, bool about_solution) {
-    const long n = (long)v.B * count * 16;
+    const unsigned blocks = blocks_for((long)v.B * count, kStagesPerBlock);
     if (about_solution)
-        hipLaunchKernelGGL(k_linearise<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, first, count);
+        hipLaunchKernelGGL(k_linearise<true>, dim3(blocks), dim3(256), 0, s, v, first, count);
     else
-        hipLaunchKernelGGL(k_linearise<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, first, count);
+        hipLaunchKernelGGL(k_linearise<false>, dim3(blocks), dim3(256), 0, s, v, first, count);
 }
 void launch_linearise_free(long n, const real_t* x, const real_t* u, const real_t* xn,
                            const real_t* w, const Bounds& bnd, real_t* jac, real_t* res,
                            hipStream_t s) {
-    hipLaunchKernelGGL(k_linearise_free, dim3(blocks_for(n * 16, 256)), dim3(256), 0, s, n, x, u, xn,
-                       w, bnd, jac, res);
+    const unsigned blocks = blocks_for(n, kStagesPerBlock);
+    if ((((uintptr_t)jac | (uintptr_t)res) & 15) == 0)
+        hipLaunchKernelGGL(k_linearise_free<true>, dim3(blocks), dim3(256), 0, s, n, x, u, xn, w, bnd, jac, res);
+    else
+        hipLaunchKernelGGL(k_linearise_free<false>, dim3(blocks), dim3(256), 0, s, n, x, u, xn, w, bnd, jac, res);
 }
 void launch_rk4_free(long n, const real_t* x, const real_t* u, const real_t* w, real_t delta,
                      real_t* out, hipStream_t s) {

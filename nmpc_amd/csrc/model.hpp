@@ -236,8 +236,11 @@ NMPC_DEV void state_model(real_t* out, const real_t* s, const real_t* u,
 
 // Classical RK4 with the reference's float-rounded 1/3 and 1/6 weights:
 // x+ = x + d3 (b + c) + d6 (a + d).
+// ta, tb (optional): the two increments of the position entries, out[i] =
+// (s[i] + ta[i]) + tb[i], i < 3.
 NMPC_DEV void rk4_step(real_t* out, const real_t* s, const real_t* u,
-                       const real_t* wind, real_t delta) {
+                       const real_t* wind, real_t delta, real_t* ta = nullptr,
+                       real_t* tb = nullptr) {
     real_t k[NS], t[NS], bc[NS], ad[NS];
     state_model(k, s, u, wind);
 #pragma unroll
@@ -251,7 +254,11 @@ NMPC_DEV void rk4_step(real_t* out, const real_t* s, const real_t* u,
     state_model(k, t, u, wind);
     const real_t d3 = delta * (1.0f / 3.0f), d6 = delta * (1.0f / 6.0f);
 #pragma unroll
-    for (int i = 0; i < NS; i++) out[i] = s[i] + d3 * bc[i] + d6 * (ad[i] + k[i]);
+    for (int i = 0; i < NS; i++) {
+        const real_t a = d3 * bc[i], b = d6 * (ad[i] + k[i]);
+        out[i] = s[i] + a + b;
+        if (i < 3 && ta) { ta[i] = a; tb[i] = b; }
+    }
 }
 
 // 12-vector difference s2 (-) s1; the attitude part is the MRP (a=1, f=4) of
