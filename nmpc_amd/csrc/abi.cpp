@@ -297,7 +297,8 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
         {(void**)&v.dl, B * N * 12 * d},    {(void**)&v.grad, B * N * 12 * d},
         {(void**)&v.ieq, B * N1 * 15},      {(void**)&v.prev, B * N1 * 15},
         {(void**)&v.chg, B * N1},           {(void**)&v.sc, B * sizeof(Scalars)},
-        {(void**)&v.tailCount, 8 * sizeof(int)}, {(void**)&v.tailList, B * sizeof(int)},
+        {(void**)&v.tailCount, 16 * sizeof(int)}, {(void**)&v.tailList, 2 * B * sizeof(int)},
+        {(void**)&v.wabs, B * N1 * 16 * d},
         {(void**)&v.C, B * N * 180 * d},
         {(void**)&v.hess, B * N * 288 * d}, {(void**)&v.chol, B * N * 288 * d},
     };
@@ -1060,4 +1061,13 @@ enum nmpc_precision_t nmpc_config_get_precision(void) {
     return sizeof(real_t) == 8 ? NMPC_PRECISION_DOUBLE : NMPC_PRECISION_FLOAT;
 }
 
+
+#ifdef NMPC_TAIL_STATS
+// Debug build only: the step-length search counters of the last solve.
+int nmpc_debug_tail_stats(nmpc_batch_t* b, int* out16) {
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(out16, b->v.tailCount, 16 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 }  // extern "C"

@@ -79,6 +79,7 @@ struct BatchView {
     real_t* qStep;
     real_t* zUnc;
     real_t* dz;
+    real_t* wabs;       // [B][N+1][16]   magnitudes behind qStep (15) and pStep (1), for k_line_search_fast
     real_t* tmp;        // trial primal vector of the line search; between solves' kernels scratch of k_newton_solve
     real_t* y;          // [B][N+1][30]   (lb - z, z - ub) pairs
     real_t* p;          // [B][N+1]
@@ -92,8 +93,9 @@ struct BatchView {
     int8_t* prev;       // [B][N+1][15]
     int8_t* chg;        // [B][N+1]       actSetHasChanged
     Scalars* sc;        // [B]
-    int* tailCount;     // [8]  instances handed to k_line_search_tail, per Newton iteration
-    int* tailList;      // [B]  their indices
+    int* tailCount;     // [16] step-length searches handed on, per Newton iteration: [0..7] by
+                        //      k_newton_step, [8..15] those k_line_search_fast left open
+    int* tailList;      // [2][B] their instances
     real_t H[15];       // regular-stage Hessian diagonal as the solver sees it
     real_t Ht[12];      // terminal-stage Hessian diagonal
     real_t lb[3], ub[3];

@@ -37,6 +37,7 @@ constexpr real_t kLsMaxStep = (real_t)1.;
 constexpr double kUnitRoundoff = sizeof(real_t) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
 
 constexpr int kWave = 64;
+constexpr int kWabsStride = 16;      // BatchView::wabs: 15 stage variables, then the stage's pStep
 
 // Ring maps.  Offsets and positions are both below the ring length, so one
 // conditional subtraction takes the place of a remainder (an integer division
@@ -57,6 +58,7 @@ struct Inst {
     const real_t* xref; const real_t* uref;
     real_t *C, *c, *zLow, *zUpp, *q, *z, *qStep, *zUnc, *dz, *tmp, *y, *p, *pStep;
     real_t *lam, *dl, *grad, *hess, *chol;
+    real_t* wabs;
     int8_t *ieq, *prev, *chg;
     Scalars* sc;
 };
@@ -76,6 +78,7 @@ NMPC_DEV Inst instance(const BatchView& v, int b) {
     I.zUnc = v.zUnc + sb * N1 * NZ;
     I.dz = v.dz + sb * N1 * NZ;
     I.tmp = v.tmp + sb * N1 * NZ;
+    I.wabs = v.wabs ? v.wabs + sb * N1 * kWabsStride : nullptr;
     I.y = v.y + sb * N1 * 2 * NZ;
     I.p = v.p + sb * N1;
     I.pStep = v.pStep + sb * N1;

@@ -605,18 +605,27 @@ NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I
             const int kk = idx / NZ, j = idx - kk * NZ, k = c0 + kk;
             if (k == N && j >= NX) continue;
             const int s = stage_slot(v, k), e = s * NZ + j;
-            real_t qs;
+            real_t qs, qa = 0.;     // qa: the same sum over magnitudes (k_line_search_fast's error bound)
             if (k < N) {
                 const real_t* Cc = I.C + (size_t)s * (NX * NZ) + j;
                 const real_t* l1 = I.dl + k * NX;
                 qs = 0.;
 #pragma unroll
-                for (int i = 0; i < NX; i++) qs += Cc[i * NZ] * l1[i];
+                for (int i = 0; i < NX; i++) {
+                    const real_t cv = Cc[i * NZ], lv = l1[i];
+                    qs += cv * lv;
+                    qa += fabs(cv) * fabs(lv);
+                }
             } else {
                 qs = 0.0;
             }
-            if (k > 0 && j < NX) qs -= I.dl[(k - 1) * NX + j];
+            if (k > 0 && j < NX) {
+                const real_t lp = I.dl[(k - 1) * NX + j];
+                qs -= lp;
+                qa += fabs(lp);
+            }
             I.qStep[e] = qs;
+            if (I.wabs) I.wabs[s * kWabsStride + j] = qa;
             const real_t d = qs / (k < N ? v.H[j] : v.Ht[j]);
             const real_t dzv = -d;
             I.dz[e] = dzv;
@@ -637,13 +646,18 @@ NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I
         __syncthreads();
         for (int k = c0 + tid; k < c1; k += kStageThreads) {
             const int s = stage_slot(v, k);
-            real_t ps = 0.;
+            real_t ps = 0., pa = 0.;
             if (k < N) {
                 const real_t* l1 = I.dl + k * NX;
 #pragma unroll
-                for (int i = 0; i < NX; i++) ps += l1[i] * I.c[s * NX + i];
+                for (int i = 0; i < NX; i++) {
+                    const real_t lv = l1[i], cv = I.c[s * NX + i];
+                    ps += lv * cv;
+                    pa += fabs(lv) * fabs(cv);
+                }
             }
             I.pStep[s] = ps;
+            if (I.wabs) I.wabs[s * kWabsStride + NZ] = pa;
             const int nV = k < N ? NZ : NX;
             const real_t* H = k < N ? v.H : v.Ht;
             const real_t pt = I.p[s] + a * ps;
@@ -719,7 +733,7 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
     const StageLds L = carve(lds_raw, v.N);
     const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
-    if (blockIdx.x == 0 && tid < 8 && v.tailCount) v.tailCount[tid] = 0;
+    if (blockIdx.x == 0 && tid < 16 && v.tailCount) v.tailCount[tid] = 0;
 
     // initial-value embedding: pin the stage-0 state to the measured deviation
     if (tid == 0) {
@@ -868,6 +882,204 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 }
 
 // ------------------------------------------------------------------------
+// First attempt at the step-length searches k_newton_step handed over: one
+// wavefront per search.
+//
+// The slope at a trial point z is  sum_k dl_k . (C_k z_k + c_k - z_{k+1}[0:12]),
+// which the reference accumulates row by row.  The search only asks whether it
+// is within the tolerance of zero and whether it is negative, and regrouped by
+// stage variable the same number is  sum_e w_e z_e + sum_k pStep_k  with
+//     w_e = (C_k' dl_k)_j - dl_{k-1,j} [j < 12, k >= 1]      for e = (stage k, variable j),
+// which is the stage-QP direction qStep the Newton step has already computed
+// (dual_qp.c:309-344): no pass over C at all.  Only the control variables and
+// the pinned state of stage 0 have finite bounds; as long as every other
+// variable stays clear of its bounds over the whole range of trial steps,
+// z_e(a) = zUnc_e + a dz_e there and their part of the sum is A + a B with two
+// numbers per search.  What is left per trial is a dot product over the 3 N + 12
+// bounded variables.
+// Rounding makes this differ from the row-ordered sum, but both stay within
+//     (rows + variables + 64) u M,   M = sum_e a_e max|z_e| + sum_k |c_k| . |dl_k|,
+//     a_e = (|C_k|' |dl_k|)_j + |dl_{k-1,j}|          (wabs, from k_newton_step)
+// of the exact sum (u = unit roundoff; at most 19 products and additions per
+// row, the rows in any order; likewise per variable, plus the rounding of the
+// trial point itself), so whenever the regrouped sum is further than twice that
+// from the tolerance threshold it answers both questions as the row-ordered sum
+// does.  A search whose next trial is not settled that way, or with an
+// unbounded variable near a bound, is left in the state it has reached to
+// k_line_search_tail, which adds in the reference's order.
+// Each round evaluates the next trial step together with every step that can
+// follow it within kTailDepth levels, like k_line_search_tail.
+template <int... I>
+NMPC_DEV void wave_sums(real_t (&x)[sizeof...(I)], std::integer_sequence<int, I...>) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ((x[I] += __shfl_xor(x[I], o)), ...);
+}
+NMPC_DEV bool clips(real_t val, real_t lo, real_t up) {
+    return (lo - val >= -kActTol) || (val - up >= -kActTol);
+}
+
+constexpr int kFastSlots = 6;       // bounded variables per lane
+static_assert(3 * kTailMaxHorizon + NX <= kFastSlots * kWave, "bounded variables must fit the wavefront");
+
+__global__ __launch_bounds__(256) void k_line_search_fast(BatchView v, int nextIt) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + threadIdx.x / kWave));
+    const int nwaves = gridDim.x * 4;
+    const int N = v.N, n = NX * N, eEnd = NZ * N + NX, nBounded = 3 * N + NX;
+    const int count = __builtin_amdgcn_readfirstlane(v.tailCount[nextIt - 2]);
+    const int s0 = stage_slot(v, 0);
+    for (int item = wave; item < count; item += nwaves) {
+        const int b = __builtin_amdgcn_readfirstlane(v.tailList[item]);    // uniform: addresses stay scalar
+        Inst I = instance(v, b);
+        Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
+        const real_t normal = I.sc->lsNormal;
+#ifdef NMPC_TAIL_STATS
+        const long long t0 = clock64();
+        int rounds = 0;
+        const int it0 = bs.it;
+#endif
+        settle(bs);
+        // no trial step lies beyond this one
+        real_t ahi = 1.;
+        if (bs.aMax > ahi) ahi = bs.aMax;
+        if (bs.aMin > ahi) ahi = bs.aMin;
+
+        // the variables without finite bounds: A, B and their share of M
+        real_t fixed[3] = {0., 0., 0.};
+        bool nearBound = false;
+        for (int e0 = lane; e0 < eEnd; e0 += 5 * kWave) {     // five values of each vector in flight
+            real_t fzu[5], fdz[5], fw[5], flo[5], fup[5], fa[5];
+            bool on[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int e = e0 + i * kWave, s = e / NZ, j = e - s * NZ;
+                on[i] = e < eEnd && j < NX && s != s0;
+                const int ec = on[i] ? e : 0, ea = on[i] ? s * kWabsStride + j : 0;
+                fzu[i] = I.zUnc[ec]; fdz[i] = I.dz[ec]; fw[i] = I.qStep[ec];
+                flo[i] = I.zLow[ec]; fup[i] = I.zUpp[ec]; fa[i] = I.wabs[ea];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (!on[i]) continue;
+                nearBound = nearBound || clips(fzu[i], flo[i], fup[i]) || clips(fzu[i] + ahi * fdz[i], flo[i], fup[i]);
+                fixed[0] += fw[i] * fzu[i];
+                fixed[1] += fw[i] * fdz[i];
+                fixed[2] += fa[i] * (fabs(fzu[i]) + ahi * fabs(fdz[i]));
+            }
+        }
+        // pStep and its magnitudes, by slot
+        for (int s = lane; s <= N; s += kWave) {
+            fixed[0] += I.pStep[s];
+            fixed[2] += I.wabs[s * kWabsStride + NZ];
+        }
+        // the bounded ones stay in registers: the state of stage 0, then the controls
+        real_t zu[kFastSlots], dzv[kFastSlots], lo[kFastSlots], up[kFastSlots], wt[kFastSlots];
+#pragma unroll
+        for (int m = 0; m < kFastSlots; m++) {
+            const int c = lane + m * kWave;
+            const bool in = c < nBounded;
+            const int k = c < NX ? 0 : (c - NX) / NU;
+            const int j = c < NX ? c : NX + (c - NX) - k * NU;
+            const int s = stage_slot(v, in ? k : 0), e = s * NZ + j;
+            zu[m] = in ? I.zUnc[e] : 0.;
+            dzv[m] = in ? I.dz[e] : 0.;
+            lo[m] = in ? I.zLow[e] : -kInfty;
+            up[m] = in ? I.zUpp[e] : kInfty;
+            wt[m] = in ? I.qStep[e] : 0.;
+            if (in) {
+                real_t y0, y1;
+                const real_t z0 = fabs(clip_gap(zu[m], lo[m], up[m], &y0, &y1));
+                const real_t z1 = fabs(clip_gap(zu[m] + ahi * dzv[m], lo[m], up[m], &y0, &y1));
+                fixed[2] += I.wabs[s * kWabsStride + j] * (z0 > z1 ? z0 : z1);
+            }
+        }
+        wave_sums(fixed, std::make_integer_sequence<int, 3>{});
+        const real_t partA = fixed[0], partB = fixed[1], bound = fixed[2];
+        bool open = __builtin_amdgcn_ballot_w64(nearBound) != 0;
+
+        // trial steps in heap order (node 1 is the next trial, nodes 2i and 2i + 1 the
+        // trials after node i when its slope is negative / positive), each reached by
+        // walking down from the root so that one search state is live at a time
+        real_t at[kTailPoints];
+        auto plan_round = [&]() {
+            const real_t at1 = bs.done ? (real_t)0. : trial_alpha(bs);
+#pragma unroll
+            for (int i = 1; i <= kTailPoints; i++) {
+                Bisection st = bs;
+                const int depth = 31 - __builtin_clz(i);
+#pragma unroll
+                for (int d = depth - 1; d >= 0; d--)
+                    if (!st.done) advance_assuming(st, ((i >> d) & 1) == 0);
+                at[i - 1] = st.done ? at1 : trial_alpha(st);
+            }
+        };
+#ifdef NMPC_TAIL_STATS
+        const long long t1 = clock64();
+#endif
+        while (!bs.done && !open) {
+#ifdef NMPC_TAIL_STATS
+            ++rounds;
+#endif
+            plan_round();
+            real_t sums[kTailPoints];
+#pragma unroll
+            for (int p = 0; p < kTailPoints; p++) {
+                sums[p] = 0.;
+#pragma unroll
+                for (int m = 0; m < kFastSlots; m++) {
+                    real_t y0, y1;
+                    sums[p] += wt[m] * clip_gap(zu[m] + at[p] * dzv[m], lo[m], up[m], &y0, &y1);
+                }
+            }
+            wave_sums(sums, std::make_integer_sequence<int, kTailPoints>{});
+#pragma unroll
+            for (int p = 0; p < kTailPoints; p++) sums[p] += partA + at[p] * partB;
+            int node = 1;
+#pragma unroll
+            for (int level = 0; level < kTailDepth; level++) {
+                if (!bs.done && !open) {
+                    real_t sv = sums[0];
+#pragma unroll
+                    for (int q = 1; q < kTailPoints; q++) sv = (q == node - 1) ? sums[q] : sv;
+                    bool flat, neg;
+                    bool settled = slope_decided(sv, bound, n + eEnd + 64, normal, &flat, &neg);
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS
+                    if (bs.it & 1) settled = false;     // test build: exercise the hand-over
+#endif
+                    if (settled) {
+                        advance_decided(bs, flat, neg);
+                        node = 2 * node + (neg ? 0 : 1);
+                    } else {
+                        open = true;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            Scalars* sc = I.sc;
+            if (open) {
+                sc->lsMin = bs.aMin; sc->lsMax = bs.aMax; sc->lsMid = bs.aMid;
+                sc->lsIter = bs.it;
+                sc->lsPhase = bs.phase;
+                const int to = atomicAdd(&v.tailCount[8 + nextIt - 2], 1);
+                v.tailList[v.B + to] = b;
+            } else {
+                sc->alpha = bs.alpha;
+                sc->lsIter = bs.it;
+            }
+#ifdef NMPC_TAIL_STATS
+            // [5] searches, [6] rounds, [7] trials, [13] set-up, [14] rounds: cycles / 256
+            atomicAdd(&v.tailCount[5], 1);
+            atomicAdd(&v.tailCount[6], rounds);
+            atomicAdd(&v.tailCount[7], bs.it - it0);
+            atomicAdd(&v.tailCount[13], (int)((t1 - t0) >> 8));
+            atomicAdd(&v.tailCount[14], (int)((clock64() - t1) >> 8));
+#endif
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // Continues the step-length searches k_newton_step handed over.  A 1024-thread
 // workgroup owns one such instance at a time: the stage vectors the trial
 // points are made of stay in registers, trial points and slope terms live in
@@ -892,9 +1104,9 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
     // gradient rows: thread t < 6 N owns rows h and h + 6 of block t / 6
     const int rk = tid / (NX / 2), rh = tid % (NX / 2);
     const bool rowOn = rk < N;
-    const int count = v.tailCount[nextIt - 2];
+    const int count = v.tailCount[8 + nextIt - 2];          // the searches k_line_search_fast left open
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        const int b = v.tailList[item];
+        const int b = v.tailList[v.B + item];
         Inst I = instance(v, b);
         Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
         const real_t normal = I.sc->lsNormal;
@@ -1108,6 +1320,7 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     if (lds > 64 * 1024)    // beyond the default cap on dynamic LDS
         (void)hipFuncSetAttribute((const void*)k_line_search_tail,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_line_search_fast, dim3((v.nb + 3) / 4), dim3(256), 0, s, v, next_it);
     hipLaunchKernelGGL(k_line_search_tail, dim3(grid), dim3(kTailThreads), lds, s, v, next_it);
     // the search kernel fills a CU with one workgroup; the two below are lighter,
     // and warm-started batches hand over half of their instances
