@@ -719,7 +719,7 @@ static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon +
 static_assert(NZ * (kTailMaxHorizon + 1) <= kTailElems * kTailThreads, "stage vectors must fit");
 static_assert(NX / 2 * kTailMaxHorizon <= kTailThreads, "two gradient rows per thread");
 NMPC_DEV bool tail_capable(const BatchView& v) {
-    return v.tailList != nullptr && v.N <= kTailMaxHorizon;
+    return v.tailList != nullptr && v.N <= 508;     // kFastHorizonLarge
 }
 inline size_t tail_lds_bytes(int N) {
     return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(real_t) + 256;
@@ -918,13 +918,20 @@ NMPC_DEV bool clips(real_t val, real_t lo, real_t up) {
     return (lo - val >= -kActTol) || (val - up >= -kActTol);
 }
 
-constexpr int kFastSlots = 6;       // bounded variables per lane
-static_assert(3 * kTailMaxHorizon + NX <= kFastSlots * kWave, "bounded variables must fit the wavefront");
+// kFastSlots bounded variables per lane in registers: 6 for horizons up to 124 (four
+// searches per 256-lane workgroup); 0 = in LDS instead, for horizons up to 508 (one
+// search per 64-lane workgroup, 60 KB).
+constexpr int kFastHorizonSmall = 124, kFastHorizonLarge = 508;
+constexpr int kFastBoxed = 3 * kFastHorizonLarge + NX;
+static_assert(3 * kFastHorizonSmall + NX <= 6 * kWave, "bounded variables must fit the wavefront");
 
-__global__ __launch_bounds__(256) void k_line_search_fast(BatchView v, int nextIt) {
+template <int kFastSlots>
+__global__ __launch_bounds__(kFastSlots ? 256 : kWave) void k_line_search_fast(BatchView v, int nextIt) {
+    __shared__ real_t box[kFastSlots ? 1 : 5][kFastSlots ? 1 : kFastBoxed];
+    constexpr int kWavesPerBlock = kFastSlots ? 4 : 1;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + threadIdx.x / kWave));
-    const int nwaves = gridDim.x * 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWavesPerBlock + threadIdx.x / kWave));
+    const int nwaves = gridDim.x * kWavesPerBlock;
     const int N = v.N, n = NX * N, eEnd = NZ * N + NX, nBounded = 3 * N + NX;
     const int count = __builtin_amdgcn_readfirstlane(v.tailCount[nextIt - 2]);
     const int s0 = stage_slot(v, 0);
@@ -972,25 +979,42 @@ __global__ __launch_bounds__(256) void k_line_search_fast(BatchView v, int nextI
             fixed[0] += I.pStep[s];
             fixed[2] += I.wabs[s * kWabsStride + NZ];
         }
-        // the bounded ones stay in registers: the state of stage 0, then the controls
-        real_t zu[kFastSlots], dzv[kFastSlots], lo[kFastSlots], up[kFastSlots], wt[kFastSlots];
-#pragma unroll
-        for (int m = 0; m < kFastSlots; m++) {
-            const int c = lane + m * kWave;
+        // the bounded ones (the state of stage 0, then the controls) stay in registers,
+        // or for long horizons in the wavefront's LDS
+        constexpr bool kInLds = kFastSlots == 0;
+        constexpr int kRegs = kInLds ? 1 : kFastSlots;
+        real_t zu[kRegs], dzv[kRegs], lo[kRegs], up[kRegs], wt[kRegs];
+        auto fetch_bounded = [&](int c, real_t (&val)[5]) {     // false: c is past the last one
             const bool in = c < nBounded;
             const int k = c < NX ? 0 : (c - NX) / NU;
             const int j = c < NX ? c : NX + (c - NX) - k * NU;
             const int s = stage_slot(v, in ? k : 0), e = s * NZ + j;
-            zu[m] = in ? I.zUnc[e] : 0.;
-            dzv[m] = in ? I.dz[e] : 0.;
-            lo[m] = in ? I.zLow[e] : -kInfty;
-            up[m] = in ? I.zUpp[e] : kInfty;
-            wt[m] = in ? I.qStep[e] : 0.;
+            val[0] = in ? I.zUnc[e] : 0.;
+            val[1] = in ? I.dz[e] : 0.;
+            val[2] = in ? I.zLow[e] : -kInfty;
+            val[3] = in ? I.zUpp[e] : kInfty;
+            val[4] = in ? I.qStep[e] : 0.;
             if (in) {
                 real_t y0, y1;
-                const real_t z0 = fabs(clip_gap(zu[m], lo[m], up[m], &y0, &y1));
-                const real_t z1 = fabs(clip_gap(zu[m] + ahi * dzv[m], lo[m], up[m], &y0, &y1));
+                const real_t z0 = fabs(clip_gap(val[0], val[2], val[3], &y0, &y1));
+                const real_t z1 = fabs(clip_gap(val[0] + ahi * val[1], val[2], val[3], &y0, &y1));
                 fixed[2] += I.wabs[s * kWabsStride + j] * (z0 > z1 ? z0 : z1);
+            }
+        };
+        if constexpr (kInLds) {
+            for (int c = lane; c < nBounded; c += kWave) {
+                real_t val[5];
+                fetch_bounded(c, val);
+#pragma unroll
+                for (int q = 0; q < 5; q++) box[q][c] = val[q];
+            }
+            // (each lane reads back only what it wrote itself)
+        } else {
+#pragma unroll
+            for (int m = 0; m < kRegs; m++) {
+                real_t val[5];
+                fetch_bounded(lane + m * kWave, val);
+                zu[m] = val[0]; dzv[m] = val[1]; lo[m] = val[2]; up[m] = val[3]; wt[m] = val[4];
             }
         }
         wave_sums(fixed, std::make_integer_sequence<int, 3>{});
@@ -1023,12 +1047,25 @@ __global__ __launch_bounds__(256) void k_line_search_fast(BatchView v, int nextI
             plan_round();
             real_t sums[kTailPoints];
 #pragma unroll
-            for (int p = 0; p < kTailPoints; p++) {
-                sums[p] = 0.;
+            for (int p = 0; p < kTailPoints; p++) sums[p] = 0.;
+            if constexpr (kInLds) {
+#pragma unroll 2
+                for (int c = lane; c < nBounded; c += kWave) {
+                    const real_t a0 = box[0][c], a1 = box[1][c], a2 = box[2][c], a3 = box[3][c], a4 = box[4][c];
 #pragma unroll
-                for (int m = 0; m < kFastSlots; m++) {
-                    real_t y0, y1;
-                    sums[p] += wt[m] * clip_gap(zu[m] + at[p] * dzv[m], lo[m], up[m], &y0, &y1);
+                    for (int p = 0; p < kTailPoints; p++) {
+                        real_t y0, y1;
+                        sums[p] += a4 * clip_gap(a0 + at[p] * a1, a2, a3, &y0, &y1);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < kTailPoints; p++) {
+#pragma unroll
+                    for (int m = 0; m < kRegs; m++) {
+                        real_t y0, y1;
+                        sums[p] += wt[m] * clip_gap(zu[m] + at[p] * dzv[m], lo[m], up[m], &y0, &y1);
+                    }
                 }
             }
             wave_sums(sums, std::make_integer_sequence<int, kTailPoints>{});
@@ -1276,6 +1313,62 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
     }
 }
 
+// The same continuation for horizons whose trial points do not fit the LDS of
+// k_line_search_tail: the trial loop of k_newton_step (one 256-thread workgroup
+// per search, trial points through global memory, row-ordered slope sums).
+__global__ __launch_bounds__(kStageThreads) void k_line_search_exact(BatchView v, int nextIt) {
+    extern __shared__ real_t lds_raw[];
+    const StageLds L = carve(lds_raw, v.N);
+    const int n = NX * v.N;
+    const int count = v.tailCount[8 + nextIt - 2];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        Inst I = instance(v, v.tailList[v.B + item]);
+        Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
+        const real_t normal = I.sc->lsNormal;
+        settle(bs);
+        while (!bs.done) {
+            stage_pass<kTrialPoint>(v, I, trial_alpha(bs), L);
+            // the slope terms summed in any order, with their magnitudes, settle the
+            // search's two questions unless the sum sits within rounding of the
+            // tolerance (slope_decided); only then are they added in row order
+            real_t sm[2] = {0., 0.};
+            for (int r = threadIdx.x; r < n; r += kStageThreads) {
+                const real_t t = gradient_row(v, I, I.tmp, r) * I.dl[r];
+                sm[0] += t;
+                sm[1] += fabs(t);
+            }
+            wave_sums(sm, std::make_integer_sequence<int, 2>{});
+            if ((threadIdx.x & (kWave - 1)) == 0) {
+                L.red[2 * (threadIdx.x / kWave)] = sm[0];
+                L.red[2 * (threadIdx.x / kWave) + 1] = sm[1];
+            }
+            __syncthreads();
+            real_t sv = 0., mv = 0.;
+#pragma unroll
+            for (int w = 0; w < kStageThreads / kWave; w++) { sv += L.red[2 * w]; mv += L.red[2 * w + 1]; }
+            __syncthreads();
+            bool flat, neg;
+            bool settled = slope_decided(sv, mv, n, normal, &flat, &neg);
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS
+            if (bs.it & 2) settled = false;         // test build: both ways
+#endif
+            if (settled) {
+                advance_decided(bs, flat, neg);
+            } else {
+                const real_t slope = block_ordered_sum(n, L, [&](int r) {
+                    return gradient_row(v, I, I.tmp, r) * I.dl[r];
+                });
+                advance(bs, slope, normal);
+            }
+        }
+        if (threadIdx.x == 0) {
+            I.sc->alpha = bs.alpha;
+            I.sc->lsIter = bs.it;
+        }
+        __syncthreads();
+    }
+}
+
 // Commit and next Newton set-up of the instances k_line_search_tail finished.
 __global__ __launch_bounds__(kStageThreads) void k_line_search_commit(BatchView v, int nextIt) {
     extern __shared__ real_t lds_raw[];
@@ -1312,16 +1405,27 @@ void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
     hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), step_lds_bytes(v.N), s, v, next_it);
 }
 bool line_search_tail_enabled(const BatchView& v) {
-    return v.tailList != nullptr && v.N <= kTailMaxHorizon;
+    return v.tailList != nullptr && v.N <= kFastHorizonLarge;
 }
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
-    const int grid = v.nb < 256 ? v.nb : 256;
-    const size_t lds = tail_lds_bytes(v.N);
-    if (lds > 64 * 1024)    // beyond the default cap on dynamic LDS
-        (void)hipFuncSetAttribute((const void*)k_line_search_tail,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_line_search_fast, dim3((v.nb + 3) / 4), dim3(256), 0, s, v, next_it);
-    hipLaunchKernelGGL(k_line_search_tail, dim3(grid), dim3(kTailThreads), lds, s, v, next_it);
+    const dim3 grid_fast((v.nb + 3) / 4);
+    if (v.N <= kFastHorizonSmall)
+        hipLaunchKernelGGL(k_line_search_fast<6>, grid_fast, dim3(256), 0, s, v, next_it);
+    else
+        hipLaunchKernelGGL(k_line_search_fast<0>, dim3(v.nb), dim3(kWave), 0, s, v, next_it);
+    // what the first attempt left open
+    if (v.N <= kTailMaxHorizon) {
+        const int grid = v.nb < 256 ? v.nb : 256;
+        const size_t lds = tail_lds_bytes(v.N);
+        if (lds > 64 * 1024)    // beyond the default cap on dynamic LDS
+            (void)hipFuncSetAttribute((const void*)k_line_search_tail,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_line_search_tail, dim3(grid), dim3(kTailThreads), lds, s, v, next_it);
+    } else {
+        const int grid = v.nb < 2048 ? v.nb : 2048;
+        hipLaunchKernelGGL(k_line_search_exact, dim3(grid), dim3(kStageThreads), stage_lds_bytes(v.N), s, v,
+                           next_it);
+    }
     // the search kernel fills a CU with one workgroup; the two below are lighter,
     // and warm-started batches hand over half of their instances
     const int grid_commit = v.nb < 2048 ? v.nb : 2048;

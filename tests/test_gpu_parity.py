@@ -513,7 +513,7 @@ sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
 from helpers import assert_same, drive_gpu_batch, golden
 from nmpc_amd import _lib
 assert _lib.LIB_PATH.endswith("libcnmpc_repeat.so")
-for name in ("seq_straight", "seq_regularised", "seq_linesearch", "seq_bound", "seq_turn0"):
+for name in ("seq_straight", "seq_regularised", "seq_linesearch", "seq_bound", "seq_turn0", "seq_n500_0"):
     g = golden(name)
     dump = "final_stages" in g
     out = drive_gpu_batch([g], dump=dump)

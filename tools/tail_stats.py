@@ -7,7 +7,7 @@ import torch
 from nmpc_amd import synthetic as S
 from nmpc_amd.batch import Batch
 
-B, N, W = 4096, 100, int(os.environ.get("WARM", "4"))
+B, N, W = int(os.environ.get("TS_B", "4096")), int(os.environ.get("TS_N", "100")), int(os.environ.get("WARM", "4"))
 dev = torch.device("cuda:0")
 d = S.make_batch(B, N, extra_steps=W, seed=S.DEFAULT_SEED)
 refs = torch.from_numpy(np.ascontiguousarray(d["refs"])).to(dev)
