@@ -214,16 +214,17 @@ NMPC_DEV void linearise_lanes(LineariseLds& L, bool active, int g, int c, const 
         const real_t p0[3] = {x[0], x[1], x[2]};
         __builtin_assume(j >= 3);                   // no lane integrates a position column
         hinv = perturb_point(x, u, j, lower, upper);
-        rk4_step(moved, x, u, wind, kStepLength, ta, tb);
+        integrate_step(moved, x, u, wind, kStepLength, ta, tb);
         if (c == 0) {
 #pragma unroll
             for (int i = 0; i < NS; i++) L.moved[g][i] = moved[i];
             // Columns 0..2 (cnmpc.c:600-606 with the perturbed entry carried
-            // through the last line of the integrator, cnmpc.c:393-397).
+            // through the last line of the integrator, cnmpc.c:393-397 for RK4).
             real_t diag[3], same[NX];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                const real_t pm = ((p0[i] + kFdStep) + ta[i]) + tb[i];
+                real_t pm = (p0[i] + kFdStep) + ta[i];
+                if constexpr (kIntegratorTerms == 2) pm = pm + tb[i];
                 diag[i] = (pm - moved[i]) * hinv;
                 same[i] = (moved[i] - moved[i]) * hinv;
                 same[3 + i] = (moved[3 + i] - moved[3 + i]) * hinv;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void k_rk4_free(long n, const real_t* __restri
     for (int i = 0; i < NS; i++) x[i] = xs[t * NS + i];
 #pragma unroll
     for (int i = 0; i < NU; i++) { u[i] = us[t * NU + i]; w[i] = winds[t * 3 + i]; }
-    rk4_step(r, x, u, w, delta);
+    integrate_step(r, x, u, w, delta);
 #pragma unroll
     for (int i = 0; i < NS; i++) out[t * NS + i] = r[i];
 }

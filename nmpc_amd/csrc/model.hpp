@@ -6,7 +6,7 @@
 //   quaternion helpers   ccs-c66x/cnmpc.c:168-240
 //   fatan2               ccs-c66x/cnmpc.c:257-280
 //   kinematics           ccs-c66x/cnmpc.c:320-363   [src/state.cpp:39-63]
-//   RK4                  ccs-c66x/cnmpc.c:365-400   [include/integrator.h:49-63]
+//   integrators          ccs-c66x/cnmpc.c:365-400   [include/integrator.h:46-91]
 //   X8 aerodynamics      ccs-c66x/cnmpc.c:402-539   [src/dynamics.cpp:33-118]
 //   state difference     ccs-c66x/cnmpc.c:541-579   [src/ocp.cpp:64-88]
 #pragma once
@@ -234,13 +234,53 @@ NMPC_DEV void state_model(real_t* out, const real_t* s, const real_t* u,
     out[10] = acc[3]; out[11] = acc[4]; out[12] = acc[5];
 }
 
-// Classical RK4 with the reference's float-rounded 1/3 and 1/6 weights:
-// x+ = x + d3 (b + c) + d6 (a + d).
-// ta, tb (optional): the two increments of the position entries, out[i] =
-// (s[i] + ta[i]) + tb[i], i < 3.
-NMPC_DEV void rk4_step(real_t* out, const real_t* s, const real_t* u,
-                       const real_t* wind, real_t delta, real_t* ta = nullptr,
-                       real_t* tb = nullptr) {
+// One integration step.  ta, tb (optional): the increments of the position
+// entries, out[i] = (s[i] + ta[i]) + tb[i] for i < 3 (tb only when
+// kIntegratorTerms == 2).
+//
+// Default: classical RK4 with the reference's float-rounded 1/3 and 1/6
+// weights, x+ = x + d3 (b + c) + d6 (a + d)  (ccs-c66x/cnmpc.c:365-400).
+// -DNMPC_INTEGRATOR_HEUN / -DNMPC_INTEGRATOR_EULER select the two cheaper
+// integrators of the reference's compile-time matrix (include/config.h:30-39).
+// They exist only in its C++ variant (include/integrator.h:66-91), whose
+// formulas these follow in real_t arithmetic; the C path has RK4 only.
+#if defined(NMPC_INTEGRATOR_HEUN)
+constexpr int kIntegratorTerms = 1;
+NMPC_DEV void integrate_step(real_t* out, const real_t* s, const real_t* u,
+                             const real_t* wind, real_t delta, real_t* ta = nullptr,
+                             real_t* tb = nullptr) {
+    real_t k1[NS], k2[NS], t[NS];
+    state_model(k1, s, u, wind);
+#pragma unroll
+    for (int i = 0; i < NS; i++) t[i] = s[i] + delta * k1[i];          // predictor
+    state_model(k2, t, u, wind);
+    const real_t half = delta * (real_t)0.5;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        const real_t a = half * (k1[i] + k2[i]);
+        out[i] = s[i] + a;
+        if (i < 3 && ta) ta[i] = a;
+    }
+}
+#elif defined(NMPC_INTEGRATOR_EULER)
+constexpr int kIntegratorTerms = 1;
+NMPC_DEV void integrate_step(real_t* out, const real_t* s, const real_t* u,
+                             const real_t* wind, real_t delta, real_t* ta = nullptr,
+                             real_t* tb = nullptr) {
+    real_t k1[NS];
+    state_model(k1, s, u, wind);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        const real_t a = delta * k1[i];
+        out[i] = s[i] + a;
+        if (i < 3 && ta) ta[i] = a;
+    }
+}
+#else
+constexpr int kIntegratorTerms = 2;
+NMPC_DEV void integrate_step(real_t* out, const real_t* s, const real_t* u,
+                             const real_t* wind, real_t delta, real_t* ta = nullptr,
+                             real_t* tb = nullptr) {
     real_t k[NS], t[NS], bc[NS], ad[NS];
     state_model(k, s, u, wind);
 #pragma unroll
@@ -260,6 +300,7 @@ NMPC_DEV void rk4_step(real_t* out, const real_t* s, const real_t* u,
         if (i < 3 && ta) { ta[i] = a; tb[i] = b; }
     }
 }
+#endif
 
 // 12-vector difference s2 (-) s1; the attitude part is the MRP (a=1, f=4) of
 // q2 (x) q1* with the real part forced non-negative.

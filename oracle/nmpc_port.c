@@ -238,12 +238,26 @@ void port_state_model(real_t *out, const real_t *s, const real_t *u,
     out[10] = acc[3]; out[11] = acc[4]; out[12] = acc[5];
 }
 
-static void axpy13(real_t *r, const real_t *d, real_t a, const real_t *s) {
+__attribute__((unused)) static void axpy13(real_t *r, const real_t *d, real_t a, const real_t *s) {
     for (int i = 0; i < NS; i++) r[i] = s[i] + d[i] * a;
 }
 
 void port_rk4(real_t *out, const real_t *s, const real_t *u, const real_t *wind,
               real_t delta) {
+#if defined(PORT_INTEGRATOR_HEUN)
+    /* include/integrator.h:66-79 (C++ variant only; the C path has RK4 only) */
+    real_t k1[NS], k2[NS], t[NS];
+    port_state_model(k1, s, u, wind);
+    for (int i = 0; i < NS; i++) t[i] = s[i] + delta * k1[i];
+    port_state_model(k2, t, u, wind);
+    real_t half = delta * (real_t)0.5;
+    for (int i = 0; i < NS; i++) out[i] = s[i] + half * (k1[i] + k2[i]);
+#elif defined(PORT_INTEGRATOR_EULER)
+    /* include/integrator.h:81-91 */
+    real_t k1[NS];
+    port_state_model(k1, s, u, wind);
+    for (int i = 0; i < NS; i++) out[i] = s[i] + delta * k1[i];
+#else
     /* cnmpc.c:365-400 */
     real_t a[NS], b[NS], c[NS], d[NS], t[NS];
     port_state_model(a, s, u, wind);
@@ -256,6 +270,7 @@ void port_rk4(real_t *out, const real_t *s, const real_t *u, const real_t *wind,
     real_t d3 = delta * (1.0f / 3.0f), d6 = delta * (1.0f / 6.0f);
     for (int i = 0; i < NS; i++)
         out[i] = s[i] + d3 * (b[i] + c[i]) + d6 * (a[i] + d[i]);
+#endif
 }
 
 void port_state_to_delta(real_t *dl, const real_t *s1, const real_t *s2) {

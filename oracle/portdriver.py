@@ -10,9 +10,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 STAGE_REC = 332
 LIB_PATH = os.path.join(HERE, "libnmpc_port.so")
-LIB_PATHS = {"double": LIB_PATH, "float": os.path.join(HERE, "libnmpc_port_f32.so")}
-DTYPES = {"double": np.float64, "float": np.float32}
-CTYPES = {"double": C.c_double, "float": C.c_float}
+# builds of the port: the two precisions, and (double precision) the Heun and
+# Euler integrators of the reference's compile-time matrix
+LIB_PATHS = {"double": LIB_PATH, "float": os.path.join(HERE, "libnmpc_port_f32.so"),
+             "heun": os.path.join(HERE, "libnmpc_port_heun.so"),
+             "euler": os.path.join(HERE, "libnmpc_port_euler.so")}
+DTYPES = {"double": np.float64, "float": np.float32, "heun": np.float64, "euler": np.float64}
+CTYPES = {"double": C.c_double, "float": C.c_float, "heun": C.c_double, "euler": C.c_double}
 
 _libs = {}
 

@@ -133,3 +133,29 @@ def test_batch_driver_matches_single(port_built):
         eu, es = p.controls()
         assert_same(u[b], eu, "controls %d" % b)
         assert st[b] == es and it[b] == p.num_iter()
+
+
+@pytest.mark.parametrize("integrator,order", [("heun", 2), ("euler", 1)])
+def test_cheaper_integrators_have_their_order(port_built, integrator, order):
+    """The Heun and Euler builds of the port (include/integrator.h:66-91; the
+    C++ variant cannot run here, so no output of it pins them: parity unpinned).
+    What can be checked without it is the method itself: against a fine RK4
+    integration, halving the step divides the one-step error by 2^(order + 1)."""
+    import numpy as np
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    x, u, w = S.random_states(64, np.random.default_rng(7))
+    ratios = []
+    for i in range(64):
+        def truth(delta):
+            s = x[i]
+            for _ in range(16):
+                s = P.rk4(s, u[i], w[i], delta / 16)
+            return s
+        h = 0.02
+        e1 = np.abs(P.rk4(x[i], u[i], w[i], h, precision=integrator) - truth(h))[3:6].max()
+        e2 = np.abs(P.rk4(x[i], u[i], w[i], h / 2, precision=integrator) - truth(h / 2))[3:6].max()
+        if e2 > 1e-13:
+            ratios.append(e1 / e2)
+    r = float(np.median(ratios))
+    assert 0.75 * 2 ** (order + 1) < r < 1.25 * 2 ** (order + 1), (integrator, r)
