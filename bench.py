@@ -45,6 +45,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# --precision float measures libcnmpc_f32.so (real_t = float, the reference's
+# shipped configuration); the library is chosen before nmpc_amd is imported
+if "--precision" in sys.argv and sys.argv[sys.argv.index("--precision") + 1:][:1] == ["float"]:
+    os.environ["NMPC_AMD_LIB"] = os.path.join(ROOT, "nmpc_amd", "libcnmpc_f32.so")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (before libcnmpc.so: see nmpc_amd/_lib.py)
 
@@ -54,6 +59,9 @@ from nmpc_amd.batch import Batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector, spec (FMA counted as 2 flop)
+FP32_VECTOR_PEAK_TF = 157.3 # MI355X fp32 vector, spec
+# arithmetic type of the loaded library: set in main()
+REAL = dict(name="f64", np=np.float64, torch=None, bytes=8, precision="double", peak_tf=FP64_VECTOR_PEAK_TF)
 METRIC = "NMPC solves/sec (prep+feedback) at batch B, default horizon"
 
 # Algorithmic work per unit, from the operation counts of the reference
@@ -104,6 +112,8 @@ def parse():
                     help="warm control steps timed after the cold solves (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the peak microbenchmarks")
+    ap.add_argument("--precision", choices=("double", "float"), default="double",
+                    help="float: measure libcnmpc_f32.so (configs 2, 4, 5)")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="units of the workload the CPU baseline processes per pass")
     a = ap.parse_args()
@@ -138,6 +148,8 @@ def load_traffic(tag, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this
     workload (tools/pmc_traffic.py), or None."""
     path = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % tag)
+    if REAL["name"] != "f64":       # the counters were collected on the double-precision library
+        return None
     if os.path.exists(path):
         return json.load(open(path)).get("bytes_per_launch", {}).get(kernel)
     return None
@@ -151,12 +163,15 @@ def make_roofline(kernel, kern, algo_bytes, peaks, traffic):
              avg_launch_ms=k["avg_ms"],
              algo_bytes_per_launch=round(algo_bytes[kernel] / max(1, k["launches"])),
              fp64_vector_TFLOPs=k["algo_TFLOPs"],
-             fp64_vector_frac=round(k["algo_TFLOPs"] / FP64_VECTOR_PEAK_TF, 5))
+             fp64_vector_frac=round(k["algo_TFLOPs"] / REAL["peak_tf"], 5))
+    if REAL["name"] != "f64":       # the same two fields under the names that fit
+        r["vector_TFLOPs"] = r.pop("fp64_vector_TFLOPs")
+        r["%s_vector_frac" % REAL["name"]] = r.pop("fp64_vector_frac")
     if peaks:
         r["peak_measured"] = peaks
         if peaks.get("hbm_triad_GBps"):
             r["frac_of_measured_hbm"] = round(achieved / peaks["hbm_triad_GBps"], 5)
-        if peaks.get("fp64_vector_no_fma_TFLOPs"):
+        if peaks.get("fp64_vector_no_fma_TFLOPs") and REAL["name"] == "f64":
             r["frac_of_measured_fp64_no_fma"] = round(
                 k["algo_TFLOPs"] / peaks["fp64_vector_no_fma_TFLOPs"], 5)
     return r
@@ -169,10 +184,12 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     B, N = a.instances, a.horizon
     # every rank draws its own instances: seed + rank
     d = S.make_batch(B, N, seed=a.seed + rank)
+    for key in ("refs", "meas", "wind"):
+        d[key] = d[key].astype(REAL["np"])
     refs = torch.from_numpy(np.ascontiguousarray(d["refs"][:, :N + 1])).to(dev)
     meas = torch.from_numpy(np.ascontiguousarray(d["meas"][:, 0])).to(dev)
     wind = torch.from_numpy(d["wind"]).to(dev)
-    out_u = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    out_u = torch.zeros((B, 3), dtype=REAL["torch"], device=dev)
     out_st = torch.zeros(B, dtype=torch.int32, device=dev)
     out_it = torch.zeros(B, dtype=torch.int32, device=dev)
 
@@ -255,9 +272,9 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     if world == 1 and a.warm_steps > 0:
         dw = S.make_batch(B, N, extra_steps=a.warm_steps, seed=a.seed + rank)
         wrefs = torch.from_numpy(np.ascontiguousarray(
-            dw["refs"][:, N + 1:].transpose(1, 0, 2))).to(dev)      # [step][B][16]
+            dw["refs"][:, N + 1:].transpose(1, 0, 2).astype(REAL["np"]))).to(dev)      # [step][B][16]
         wmeas = torch.from_numpy(np.ascontiguousarray(
-            dw["meas"][:, 1:].transpose(1, 0, 2))).to(dev)          # [step][B][13]
+            dw["meas"][:, 1:].transpose(1, 0, 2).astype(REAL["np"]))).to(dev)          # [step][B][13]
         wm = [torch.cuda.Event(enable_timing=True) for _ in range(a.warm_steps + 1)]
         bt.update_horizon(wrefs[0])
         torch.cuda.synchronize(dev)
@@ -302,7 +319,7 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
             if name not in work:
                 kern[name] = dict(total_ms=round(ms, 3), launches=int(n), avg_ms=round(ms / n, 4))
                 continue
-            nbytes = sum(al["bytes"] * u for al, u in work[name])
+            nbytes = sum(al["bytes"] * u for al, u in work[name]) * REAL["bytes"] / 8.0
             nflop = sum(al["flop"] * u for al, u in work[name])
             algo_bytes[name] = nbytes
             kern[name] = dict(total_ms=round(ms, 3), launches=int(n), avg_ms=round(ms / n, 4),
@@ -320,7 +337,8 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     roofline = make_roofline(dominant, kern, algo_bytes, peaks, load_traffic(tag, dominant))
     # the stage linearisation beside it, whichever kernel dominates
     if "linearise" in kern and dominant != "linearise":
-        lin_bytes = {"linearise": ALGO["linearise"]["bytes"] * B * N * kern["linearise"]["launches"]}
+        lin_bytes = {"linearise": ALGO["linearise"]["bytes"] * REAL["bytes"] / 8.0 * B * N
+                                  * kern["linearise"]["launches"]}
         roofline["linearise"] = make_roofline("linearise", kern, lin_bytes, None,
                                               load_traffic(tag, "linearise"))
 
@@ -338,7 +356,7 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
             cu, cst, cit, s1 = P.batch_cold_solve(
                 N, cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
                 cfg["lower_control_bound"], cfg["upper_control_bound"], d["refs"][:n, :N + 1],
-                d["meas"][:n, 0], d["wind"][:n], threads=cores)
+                d["meas"][:n, 0], d["wind"][:n], threads=cores, precision=REAL["precision"])
             secs += s1
             passes += 1
         parity = bool(np.array_equal(cu, u[:n]) and np.array_equal(cst, st[:n])
@@ -358,11 +376,11 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
             "p50_step_ms": round(percentile(step_ms, 0.5), 4),
             "p99_step_ms": round(percentile(step_ms, 0.99), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": REAL["name"], "data": "synthetic",
             "config": {"workload": "%d independent UAV NMPC instances per GPU, horizon %d, "
                                    "cold solve (reset, init, %d reference points = all stages "
-                                   "linearised, feedback, get controls), fp64"
-                                   % (B, N, N + 1),
+                                   "linearised, feedback, get controls), %s"
+                                   % (B, N, N + 1, REAL["name"]),
                        "baseline_config": a.config,
                        "instances_per_gpu": B, "horizon": N, "total_instances": total_instances,
                        "parallelism": "instance partition, %d GPU(s)" % world},
@@ -386,16 +404,16 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
 def run_samples(a, world, rank, local, dev, dist, peaks):
     n = a.samples
     rng = np.random.default_rng(a.seed + rank)
-    x, u, w = S.random_states(n, rng)
+    x, u, w = (v.astype(REAL["np"]) for v in S.random_states(n, rng))
     xn = np.roll(x, 1, axis=0)
-    lo, up = np.zeros(3), np.ones(3)
+    lo, up = np.zeros(3, REAL["np"]), np.ones(3, REAL["np"])
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     tx, tu, tn, tw = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, u, xn, w))
-    jac = torch.empty((n, 180), dtype=torch.float64, device=dev)
-    res = torch.empty((n, 12), dtype=torch.float64, device=dev)
+    jac = torch.empty((n, 180), dtype=REAL["torch"], device=dev)
+    res = torch.empty((n, 12), dtype=REAL["torch"], device=dev)
     lib = _lib.load()
-    plo, pup = lo.ctypes.data_as(_lib.PREAL), up.ctypes.data_as(_lib.PREAL)
+    plo, pup = lo.ctypes.data_as(lib.preal), up.ctypes.data_as(lib.preal)
     ptr = lambda t: C.c_void_p(t.data_ptr())
     hs = C.c_void_p(stream.cuda_stream)
 
@@ -424,7 +442,7 @@ def run_samples(a, world, rank, local, dev, dist, peaks):
         elapsed = float(t.item())
     step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
     avg_ms = sum(step_ms) / len(step_ms)
-    al = ALGO["linearise"]
+    al = dict(flop=ALGO["linearise"]["flop"], bytes=ALGO["linearise"]["bytes"] * REAL["bytes"] / 8.0)
     kern = {"linearise": dict(total_ms=round(sum(step_ms), 3), launches=a.steps,
                               avg_ms=round(avg_ms, 4),
                               algo_GBps=round(al["bytes"] * n / 1e9 / (avg_ms / 1e3), 1),
@@ -440,7 +458,8 @@ def run_samples(a, world, rank, local, dev, dist, peaks):
         m = min(a.cpu_sample or (1 << 18), n)
         secs, passes = 0.0, 0
         while secs < 1.5 and passes < 16:
-            cj, cr, s1 = P.batch_linearise(x[:m], u[:m], xn[:m], w[:m], lo, up, threads=cores)
+            cj, cr, s1 = P.batch_linearise(x[:m], u[:m], xn[:m], w[:m], lo, up, threads=cores,
+                                           precision=REAL["precision"])
             secs += s1
             passes += 1
         gj, gr = jac[:m].cpu().numpy(), res[:m].cpu().numpy()
@@ -458,11 +477,11 @@ def run_samples(a, world, rank, local, dev, dist, peaks):
         "ms_per_step": round(elapsed / a.steps * 1e3, 4),
         "p50_step_ms": round(percentile(step_ms, 0.5), 4),
         "p99_step_ms": round(percentile(step_ms, 0.99), 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": REAL["name"],
         "data": "synthetic",
         "config": {"workload": "%d independent (x, u, wind) samples per GPU through the stage "
                                "linearisation (1 nominal + 15 perturbed RK4 integrations, "
-                               "12x15 Jacobian and residual out), fp64" % n,
+                               "12x15 Jacobian and residual out), %s" % (n, REAL["name"]),
                    "baseline_config": 5, "samples_per_gpu": n,
                    "parallelism": "sample partition, %d GPU(s)" % world},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
@@ -586,6 +605,13 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    REAL["torch"] = torch.float64
+    if a.precision == "float":
+        if a.config == 1:
+            sys.exit("--precision float: configs 2, 4 and 5 only")
+        assert _lib.load().np_real == "float32", "libcnmpc_f32.so was not the library loaded"
+        REAL.update(name="f32", np=np.float32, torch=torch.float32, bytes=4, precision="float",
+                    peak_tf=FP32_VECTOR_PEAK_TF)
     # Rehearsal of the multi-rank path on a box with fewer GPUs than ranks:
     # NMPC_BENCH_REHEARSE=1 lets ranks share GPUs and gathers over gloo (RCCL
     # refuses two ranks on one device).  Never set for a measurement.
