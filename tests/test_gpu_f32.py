@@ -50,36 +50,37 @@ for b, g in enumerate(gs):
     assert_same(out["u"][b], g["u"], "batched turn%%d controls" %% b)
     assert_same(out["iters"][b], g["iters"], "batched turn%%d iterations" %% b)
 
-# a seeded batch, cold solve and two warm steps, against the single-precision port
+# seeded batches, cold solve and warm steps, against the single-precision port: the
+# default horizon, and one beyond the range of the 1024-lane step-length search kernel
 import portdriver as P
 from nmpc_amd import synthetic as S
-N, B, steps = 100, 300, 3
-d = S.make_batch(B, N, extra_steps=steps, seed=808)
-cfg = S.setup_args()
-bt = Batch(B, N); bt.setup(**cfg); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
-bt.set_reference(d["refs"][:, :N + 1])
-ports = []
-for b in range(B):
-    p = P.Port(N, "float")
-    p.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
-            cfg["upper_control_bound"], cfg["lower_control_bound"])
-    p.init(); p.set_wind(d["wind"][b])
-    for i in range(N + 1):
-        p.set_reference(d["refs"][b, i], i)
-    ports.append(p)
-converged = 0
-for k in range(steps):
-    bt.solve(d["meas"][:, k])
-    u, st, it = bt.get_controls()
-    for b, p in enumerate(ports):
-        p.feedback(d["meas"][b, k])
-        eu, es = p.controls()
-        assert np.array_equal(u[b], eu) and st[b] == es and it[b] == p.num_iter(), (k, b, u[b], eu, st[b], es, it[b], p.num_iter())
-        p.update_horizon(d["refs"][b, N + 1 + k])
-    converged += int((st == 0).sum())
-    bt.update_horizon(d["refs"][:, N + 1 + k])
-assert converged > B
-bt.close()
+for N, B, steps, seed in ((100, 300, 3, 808), (150, 24, 2, 809)):
+    d = S.make_batch(B, N, extra_steps=steps, seed=seed)
+    cfg = S.setup_args()
+    bt = Batch(B, N); bt.setup(**cfg); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    ports = []
+    for b in range(B):
+        p = P.Port(N, "float")
+        p.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        p.init(); p.set_wind(d["wind"][b])
+        for i in range(N + 1):
+            p.set_reference(d["refs"][b, i], i)
+        ports.append(p)
+    converged = 0
+    for k in range(steps):
+        bt.solve(d["meas"][:, k])
+        u, st, it = bt.get_controls()
+        for b, p in enumerate(ports):
+            p.feedback(d["meas"][b, k])
+            eu, es = p.controls()
+            assert np.array_equal(u[b], eu) and st[b] == es and it[b] == p.num_iter(), (N, k, b, u[b], eu, st[b], es, it[b], p.num_iter())
+            p.update_horizon(d["refs"][b, N + 1 + k])
+        converged += int((st == 0).sum())
+        bt.update_horizon(d["refs"][:, N + 1 + k])
+    assert converged > B // 2, (N, converged)
+    bt.close()
 print("child ok")
 """
 
