@@ -270,7 +270,7 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     # horizon by one reference point (which linearises one stage).
     warm = None
     if world == 1 and a.warm_steps > 0:
-        dw = S.make_batch(B, N, extra_steps=a.warm_steps, seed=a.seed + rank)
+        dw = S.make_batch(B, N, extra_steps=2 * a.warm_steps, seed=a.seed + rank)
         wrefs = torch.from_numpy(np.ascontiguousarray(
             dw["refs"][:, N + 1:].transpose(1, 0, 2).astype(REAL["np"]))).to(dev)      # [step][B][16]
         wmeas = torch.from_numpy(np.ascontiguousarray(
@@ -292,6 +292,25 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
                     p99_ms=round(percentile(wms, 0.99), 4),
                     steps_per_s=round(B * a.warm_steps / (sum(wms) / 1e3), 1),
                     ok_frac=round(float((out_st.cpu().numpy() == 0).mean()), 4))
+        # the same loop with the real-time-iteration preparation step: every stage
+        # re-linearised about the last solution before each feedback step
+        bt.set_rti(True)
+        bt.update_horizon(wrefs[a.warm_steps])
+        torch.cuda.synchronize(dev)
+        wm[0].record(stream)
+        for k in range(a.warm_steps):
+            bt.prepare()
+            bt.solve(wmeas[a.warm_steps + k])
+            bt.get_controls_into(out_u, out_st, out_it)
+            if k + 1 < a.warm_steps:
+                bt.update_horizon(wrefs[a.warm_steps + k + 1])
+            wm[k + 1].record(stream)
+        torch.cuda.synchronize(dev)
+        bt.set_rti(False)
+        rms = sorted(wm[k].elapsed_time(wm[k + 1]) for k in range(a.warm_steps))
+        warm["rti"] = dict(p50_ms=round(percentile(rms, 0.5), 4), p99_ms=round(percentile(rms, 0.99), 4),
+                           ok_frac=round(float((out_st.cpu().numpy() == 0).mean()), 4),
+                           mean_qp_iterations=round(float(out_it.float().mean()), 3))
 
     # ---- roofline of the dominant kernel (rank 0's GPU) ----------------------
     # units each launch kind processed over the timed steps

@@ -197,14 +197,18 @@ int nmpc_batch_preparation_step(nmpc_batch_t *b);
 
 /* Real-time-iteration mode (default off; no counterpart in the reference's
  * code, whose preparation step is empty although its comments assign it this
- * work: src/ocp.cpp:245-250, 315-322).  While on, the preparation step
- * linearises every stage that carries a solution of the last feedback step
- * about that solution, x = x_ref[k] (+) z_k[0:12], u = u_ref[k] + z_k[12:15],
- * instead of about the reference trajectory, with C_k = d f / d (x, u) there
- * and c_k = delta(x_ref[k+1], f(x, u)) - C_k z_k, and re-stages it.  Stages a
- * reference point has linearised since the last feedback step (the new last
- * stage after nmpc_batch_update_horizon) are left as they are.  Results then
- * differ from the reference's; oracle/nmpc_port.c defines the arithmetic. */
+ * work: src/ocp.cpp:245-250, 315-322).  While on, the preparation step after a
+ * feedback step that ended with NMPC_OK linearises every stage again: a stage
+ * that carries a solution about that solution, x = x_ref[k] (+) z_k[0:12],
+ * u = u_ref[k] + z_k[12:15], with C_k = d f / d (x, u) there and
+ * c_k = delta(x_ref[k+1], f(x, u)) - C_k z_k; a stage a reference point has
+ * linearised since (the new last stage after nmpc_batch_update_horizon) about
+ * the reference as before.  The multipliers and the constant terms of the stage
+ * objectives restart from zero and every stage is re-staged against them
+ * (multipliers of the old linearisation are a worse start for the dual Newton
+ * iteration than none).  After a feedback step that did not converge the
+ * instance is left exactly as it is.  Results then differ from the
+ * reference's; oracle/nmpc_port.c defines the arithmetic. */
 int nmpc_batch_set_rti(nmpc_batch_t *b, int enabled);
 
 /* Re-linearisation of every stage about the stored reference trajectory with

@@ -560,18 +560,32 @@ int nmpc_batch_preparation_step(nmpc_batch_t* b) {
     sync_config(b);
     TRY(materialise_jacobians(b));
     if (b->stage_zero_pending) TRY(materialise_stage_vectors(b));
-    // runs of horizon positions that carry a solution of the last feedback step
+    // Nothing to do unless some stage carries a solution of the last feedback step.
     const int N = b->v.N;
+    if (std::find(b->fresh.begin(), b->fresh.begin() + N, 0) == b->fresh.begin() + N) return 0;
+    // Per instance, on the device: an instance whose last solve did not converge
+    // is left exactly as it is (no solution to linearise about, and its
+    // multipliers are the progress made so far).  For the others every stage is
+    // linearised again, about its solution where it has one and about the
+    // reference otherwise, and the duals start afresh: multipliers of the old
+    // linearisation would, with Jacobians that moved, put the stage solutions
+    // into the control bounds all along the horizon, and the dual Newton
+    // iteration then needs more than its five steps to recover.
+    const BatchView& v = b->v;
+    TRY(timed(b, NMPC_K_OTHER, [&] {
+        launch_rti_reset(v, b->stream);
+        launch_init_stages(v, 3, b->stream);    // terminal stage against the new multipliers
+    }));
     for (int k = 0; k < N;) {
-        if (b->fresh[k]) { ++k; continue; }
+        const bool about_solution = !b->fresh[k];
         int e = k;
-        while (e < N && !b->fresh[e]) ++e;
+        while (e < N && !b->fresh[e] == about_solution) ++e;
         TRY(timed(b, NMPC_K_LINEARISE, [&] {
-            launch_linearise(b->v, k, e - k, b->stream, true);
+            launch_linearise(b->v, k, e - k, b->stream, about_solution, true);
         }));
-        std::fill(b->fresh.begin() + k, b->fresh.begin() + e, 1);
         k = e;
     }
+    std::fill(b->fresh.begin(), b->fresh.begin() + N, 1);
     return 0;
 }
 

@@ -103,7 +103,8 @@ __global__ void k_store_refs(BatchView v, const real_t* __restrict__ refs,
 // Linearising a stage rewrites every vector this kernel writes for it, so the
 // host runs the kernel in two parts: the active-set record and the terminal
 // stage at once (part 1), the stages 0..N-1 (part 2) only if something turns up
-// that reads them before every stage has been linearised.
+// that reads them before every stage has been linearised.  Part 3 is part 1 for
+// the instances whose last solve converged (real-time-iteration preparation).
 __global__ void k_init_stages(BatchView v, int part) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = (v.N + 1) * NZ;
@@ -111,6 +112,10 @@ __global__ void k_init_stages(BatchView v, int part) {
     const int b = (int)(t / per), r = (int)(t % per);
     const int k = r / NZ, i = r - k * NZ;
     Inst I = instance(v, b);
+    if (part == 3) {
+        if (I.sc->lastResult == 0) return;
+        part = 1;
+    }
     if (part == 1) I.prev[r] = -42;
     if ((part == 1) != (k == v.N)) return;
     const int nV = k < v.N ? NZ : NX;
@@ -269,6 +274,7 @@ NMPC_DEV void store_tiles(const LineariseLds& L, int nvalid, real_t* jac, real_t
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     for (int gg = wave; gg < nvalid; gg += 4) {
         const long row = row_of(gg);                // the same for the whole wavefront
+        if (row < 0) continue;
         real_t* jr = jac + row * (NX * NZ);
         real_t* rr = res + row * NX;
         const real_t* tl = L.tile[gg];
@@ -300,13 +306,17 @@ NMPC_DEV void store_tiles(const LineariseLds& L, int nvalid, real_t* jac, real_t
 // current solution z and the residual is taken back by C z, so that the stage
 // stays a deviation from the reference: c = delta(x_ref[k+1], f(x, u)) - C z
 // (the real-time-iteration preparation step; the reference has no code for it).
+// only_solved: the stages of instances whose last solve did not converge are
+// left as they are.
 template <bool ABOUT_SOLUTION>
-__global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchView v, int first, int count) {
+__global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchView v, int first, int count,
+                                                                         int only_solved) {
     __shared__ LineariseLds L;
     const int t = threadIdx.x, g = t / kLanesPerStage, c = t - g * kLanesPerStage;
     const long total = (long)v.B * count;
     const long st = (long)blockIdx.x * kStagesPerBlock + g;
-    const bool active = g < kStagesPerBlock && st < total;
+    bool active = g < kStagesPerBlock && st < total;
+    if (active && only_solved) active = v.sc[(unsigned)st / (unsigned)count].lastResult != 0;
     if (t == 0) {                   // kernel arguments: static indices only
 #pragma unroll
         for (int i = 0; i < NZ; i++) L.H[i] = v.H[i];
@@ -343,6 +353,8 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
             if (c < NZ - kLanesPerStage) L.z[g][kLanesPerStage + c] = zw;
         }
         if (c == 0) { L.row[g] = b * v.N + s; L.inst[g] = b; L.pos[g] = k; L.slot[g] = s; }
+    } else if (c == 0 && g < kStagesPerBlock) {
+        L.row[g] = -1;                              // no tile to store for this group
     }
     __syncthreads();
     real_t col[NX];
@@ -495,6 +507,18 @@ __global__ void k_gather_results(BatchView v, real_t* __restrict__ out_u,
     out_iters[b] = sc->numIter;
 }
 
+// Real-time-iteration preparation: multipliers and the constant terms of the stage
+// objectives of every instance whose last solve converged return to zero.
+__global__ void k_rti_reset(BatchView v) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = v.N * NX + v.N + 1;
+    if (t >= (long)v.B * per) return;
+    const int b = (int)(t / per), r = (int)(t - (long)b * per);
+    if (v.sc[b].lastResult == 0) return;
+    if (r < v.N * NX) v.lam[(size_t)b * v.N * NX + r] = 0.;
+    else v.p[(size_t)b * (v.N + 1) + (r - v.N * NX)] = 0.;
+}
+
 // ========================================================================
 // launchers
 // ========================================================================
@@ -514,12 +538,18 @@ void launch_init_stages(const BatchView& v, int part, hipStream_t s) {
     const long n = (long)v.B * (v.N + 1) * NZ;
     hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, part);
 }
-void launch_linearise(const BatchView& v, int first, int count, hipStream_t s, bool about_solution) {
+void launch_linearise(const BatchView& v, int first, int count, hipStream_t s, bool about_solution,
+                      bool only_solved) {
     const unsigned blocks = blocks_for((long)v.B * count, kStagesPerBlock);
     if (about_solution)
-        hipLaunchKernelGGL(k_linearise<true>, dim3(blocks), dim3(256), 0, s, v, first, count);
+        hipLaunchKernelGGL(k_linearise<true>, dim3(blocks), dim3(256), 0, s, v, first, count, 1);
     else
-        hipLaunchKernelGGL(k_linearise<false>, dim3(blocks), dim3(256), 0, s, v, first, count);
+        hipLaunchKernelGGL(k_linearise<false>, dim3(blocks), dim3(256), 0, s, v, first, count,
+                           only_solved ? 1 : 0);
+}
+void launch_rti_reset(const BatchView& v, hipStream_t s) {
+    const long n = (long)v.B * (v.N * NX + v.N + 1);
+    hipLaunchKernelGGL(k_rti_reset, dim3(blocks_for(n, 256)), dim3(256), 0, s, v);
 }
 void launch_linearise_free(long n, const real_t* x, const real_t* u, const real_t* xn,
                            const real_t* w, const Bounds& bnd, real_t* jac, real_t* res,

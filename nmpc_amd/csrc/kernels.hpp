@@ -14,7 +14,8 @@ void launch_refs_from_waypoints(int B, const real_t* wp, int W, real_t t0, real_
 void launch_init_stages(const BatchView& v, int part, hipStream_t s);
 // about_solution: expansion point moved by each stage's current z (see k_linearise)
 void launch_linearise(const BatchView& v, int first, int count, hipStream_t s,
-                      bool about_solution = false);
+                      bool about_solution = false, bool only_solved = false);
+void launch_rti_reset(const BatchView& v, hipStream_t s);
 void launch_linearise_free(long n, const real_t* x, const real_t* u, const real_t* xnext,
                            const real_t* wind, const Bounds& bnd, real_t* jac, real_t* res,
                            hipStream_t s);

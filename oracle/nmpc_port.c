@@ -883,8 +883,15 @@ void port_feedback_step(port_t *p, const real_t *meas) {
  * composition the finite differences use (cnmpc.c:617-634) with the scalar part
  * in its intended form (16 - p.p) / (16 + p.p) (src/ocp.cpp:122-126).  The stage
  * keeps its meaning as a deviation from the reference:
- *     C_k = d f / d (x, u) at (x, u),   c_k = delta(x_ref[k+1], f(x, u)) - C_k z_k,
- * and is re-staged like any stage whose data changed (setup_qp.c:415-474).
+ *     C_k = d f / d (x, u) at (x, u),   c_k = delta(x_ref[k+1], f(x, u)) - C_k z_k.
+ * Stages without a solution are linearised about the reference again.  The
+ * multipliers restart from zero, every stage is re-staged against them
+ * (setup_qp.c:547-585) and the constant terms of the stage objectives return to
+ * zero: multipliers of the old linearisation put the stage solutions into the
+ * control bounds all along the horizon, which costs the dual Newton iteration
+ * more than its five steps, while from zero it needs two to four.  When the
+ * last feedback step did not end with NMPC_OK its stage variables are no
+ * solution, and the stages are linearised at zero deviation instead.
  */
 void port_state_plus_delta(real_t *out, const real_t *x, const real_t *d) {
     for (int i = 0; i < 3; i++) {
@@ -901,22 +908,35 @@ void port_state_plus_delta(real_t *out, const real_t *x, const real_t *d) {
 }
 
 void port_preparation_step_rti(port_t *p) {
-    int N = p->N;
+    int N = p->N, any = 0;
+    for (int k = 0; k < N; k++) any |= !stage_at(p, k)->fresh;
+    if (!any) return;
+    /* An unconverged solve left no solution to linearise about, and its
+     * multipliers are the progress made so far: nothing changes, the next
+     * feedback step carries on from there as it does without this step. */
+    if (!p->lastResult) return;
     for (int k = 0; k < N; k++) {
         stage_t *s = stage_at(p, k);
-        if (s->fresh) continue;
-        real_t x[NS], u[NU];
-        port_state_plus_delta(x, &p->xref[k * NS], s->z);
-        for (int i = 0; i < NU; i++) u[i] = p->uref[k * NU + i] + s->z[NX + i];
-        port_linearise(x, u, &p->xref[(k + 1) * NS], p->wind, p->lb, p->ub, s->C, s->c);
-        for (int r = 0; r < NX; r++) {
-            real_t acc = 0.;
-            for (int j = 0; j < NZ; j++) acc += s->C[r * NZ + j] * s->z[j];
-            s->c[r] = s->c[r] - acc;
+        if (s->fresh) {     /* entered the horizon since: about the reference, as it was */
+            port_linearise(&p->xref[k * NS], &p->uref[k * NU], &p->xref[(k + 1) * NS], p->wind, p->lb,
+                           p->ub, s->C, s->c);
+        } else {
+            real_t x[NS], u[NU];
+            port_state_plus_delta(x, &p->xref[k * NS], s->z);
+            for (int i = 0; i < NU; i++) u[i] = p->uref[k * NU + i] + s->z[NX + i];
+            port_linearise(x, u, &p->xref[(k + 1) * NS], p->wind, p->lb, p->ub, s->C, s->c);
+            for (int r = 0; r < NX; r++) {
+                real_t acc = 0.;
+                for (int j = 0; j < NZ; j++) acc += s->C[r * NZ + j] * s->z[j];
+                s->c[r] = s->c[r] - acc;
+            }
         }
-        restage(p, k);
-        s->fresh = 1;
     }
+    /* the duals, and the constant terms that follow them, start afresh */
+    memset(p->lambda, 0, sizeof(real_t) * (size_t)N * NX);
+    for (int k = 0; k <= N; k++) { stage_at(p, k)->p = 0.; restage(p, k); }
+    for (int k = 0; k < N; k++) stage_at(p, k)->fresh = 1;
+    mark_data_changed(p);
 }
 
 int port_get_controls(port_t *p, real_t *u) {

@@ -15,7 +15,7 @@ def test_rti_preparation_matches_the_port(port_built):
     import portdriver as P
     from nmpc_amd import synthetic as S
     from nmpc_amd.batch import Batch
-    N, B, steps = 30, 7, 6
+    N, B, steps = 30, 24, 8
     d = S.make_batch(B, N, extra_steps=steps, seed=616, turn_start=(0.05, 0.4))
     cfg = S.setup_args()
 
@@ -42,6 +42,10 @@ def test_rti_preparation_matches_the_port(port_built):
     got, gst, ggl = gpu(True)
     plain, _, _ = gpu(False)
     differs = False
+    # both kinds of instance must occur: after a converged solve everything is
+    # linearised again, after an unconverged one the instance is left alone
+    status = np.stack([got[k][1] for k in range(steps)])
+    assert (status[:-1] == 0).any() and (status[:-1] != 0).any(), status
     for b in range(B):
         c = P.Port(N)
         c.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
