@@ -92,6 +92,9 @@ def test_batch_argument_errors_without_gpu():
     assert lib.nmpc_batch_create(ctypes.byref(h), 0, 100, 0, None) == -1   # NMPC_E_ARG
     assert b"instances" in lib.nmpc_last_error()
     assert lib.nmpc_batch_create(None, 1, 100, 0, None) == -1
+    # the kernels index (instance, stage) pairs with 32-bit integers
+    assert lib.nmpc_batch_create(ctypes.byref(h), 1 << 24, 127, 0, None) == -1
+    assert b"2^31" in lib.nmpc_last_error()
     assert lib.nmpc_batch_feedback_step(None, None) == -1
 
 
