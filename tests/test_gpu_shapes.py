@@ -68,3 +68,51 @@ def test_bounds_changed_between_init_and_partial_reference_loading(port_built):
         exp = c.stages()
         assert_same(got[b], exp, "stage records, instance %d" % b)
         assert (exp[6, 204:207] == 0.0).all() and (exp[1, 204:207] != 0.0).all()
+
+
+@pytest.mark.parametrize("B,N,steps,seed", [(1024, 100, 5, 4242), (96, 500, 3, 4343)])
+def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
+    """Control loop (feedback, controls, horizon shift) of a whole batch against the
+    port, instance by instance: warm steps are where half of the instances go
+    through the handed-over step-length searches (the regrouped first attempt and
+    the row-ordered continuation; at N = 500 their long-horizon forms)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    d = S.make_batch(B, N, extra_steps=steps, seed=seed)
+    cfg = S.setup_args()
+    bt = Batch(B, N)
+    bt.setup(**cfg)
+    bt.initialise_horizon()
+    bt.set_wind_velocity(d["wind"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    got = []
+    for k in range(steps):
+        bt.solve(d["meas"][:, k])
+        got.append(bt.get_controls())
+        bt.update_horizon(d["refs"][:, N + 1 + k])
+    bt.close()
+
+    def one(b):
+        p = P.Port(N)
+        p.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        p.init()
+        p.set_wind(d["wind"][b])
+        for i in range(N + 1):
+            p.set_reference(d["refs"][b, i], i)
+        out = []
+        for k in range(steps):
+            p.feedback(d["meas"][b, k])
+            u, st = p.controls()
+            out.append((u, st, p.num_iter()))
+            p.update_horizon(d["refs"][b, N + 1 + k])
+        return out
+    with ThreadPoolExecutor(8) as pool:       # the port's calls release the interpreter lock
+        exp = list(pool.map(one, range(B)))
+    bad = [(b, k) for b in range(B) for k in range(steps)
+           if not (np.array_equal(got[k][0][b], exp[b][k][0]) and got[k][1][b] == exp[b][k][1]
+                   and got[k][2][b] == exp[b][k][2])]
+    assert not bad, bad[:10]
+    assert sum(int((g[1] == 0).sum()) for g in got) > B * steps // 4      # the comparison is not vacuous
