@@ -14,6 +14,12 @@
 //                  (dual_qp.c:423-597).  It is fused behind the kernels above so
 //                  that instances that are done stepping go on while others are
 //                  still in their line search.
+//   k_line_search_fast / _tail / _exact / _commit / _hessian
+//                  step-length searches that go on after their first bisection
+//                  trial (dual_qp.c:1341-1470), handed over by k_newton_step: a
+//                  first attempt on a regrouped slope with a rounding bound, the
+//                  row-ordered continuation of what that leaves open, then the
+//                  commit and the Newton set-up of those instances
 //
 // Element-wise stage work (step, clip, gaps, linear term) runs over the flat
 // slot-ordered index e = 15 slot + i, so global accesses are contiguous across
