@@ -1,0 +1,45 @@
+"""Soak: warm control steps of whole batches on the GPU against the CPU port, bit for bit.
+usage: python tools/soak_warm.py B N steps seed [B N steps seed ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from concurrent.futures import ThreadPoolExecutor
+import numpy as np
+import portdriver as P
+from nmpc_amd import synthetic as S
+from nmpc_amd.batch import Batch
+
+PREC = os.environ.get("SOAK_PRECISION", "double")     # float: with NMPC_AMD_LIB=.../libcnmpc_f32.so
+BOUNDS = os.environ.get("SOAK_TIGHT_BOUNDS")           # narrow control bounds: many active constraints
+args = [int(a) for a in sys.argv[1:]]
+for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
+    d = S.make_batch(B, N, extra_steps=steps, seed=seed)
+    cfg = S.setup_args()
+    if BOUNDS:
+        cfg.update(upper_control_bound=[0.62, 0.55, 0.55], lower_control_bound=[0.4, 0.45, 0.45])
+    bt = Batch(B, N); bt.setup(**cfg); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
+    bt.set_reference(d["refs"][:, :N + 1])
+    got = []
+    for k in range(steps):
+        bt.solve(d["meas"][:, k]); got.append(bt.get_controls()); bt.update_horizon(d["refs"][:, N + 1 + k])
+    bt.close()
+
+    def one(b):
+        p = P.Port(N, PREC)
+        p.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        p.init(); p.set_wind(d["wind"][b])
+        for i in range(N + 1):
+            p.set_reference(d["refs"][b, i], i)
+        out = []
+        for k in range(steps):
+            p.feedback(d["meas"][b, k]); u, st = p.controls(); out.append((u, st, p.num_iter()))
+            p.update_horizon(d["refs"][b, N + 1 + k])
+        return out
+    with ThreadPoolExecutor(16) as pool:
+        exp = list(pool.map(one, range(B)))
+    bad = [(b, k) for b in range(B) for k in range(steps)
+           if not (np.array_equal(got[k][0][b], exp[b][k][0]) and got[k][1][b] == exp[b][k][1]
+                   and got[k][2][b] == exp[b][k][2])]
+    ok = sum(int((g[1] == 0).sum()) for g in got)
+    print(PREC, "tight" if BOUNDS else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5], flush=True)
