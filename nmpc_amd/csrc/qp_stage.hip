@@ -725,7 +725,7 @@ static_assert(kTailPoints * (NZ * (kTailMaxHorizon + 1) + NX * kTailMaxHorizon +
 static_assert(NZ * (kTailMaxHorizon + 1) <= kTailElems * kTailThreads, "stage vectors must fit");
 static_assert(NX / 2 * kTailMaxHorizon <= kTailThreads, "two gradient rows per thread");
 NMPC_DEV bool tail_capable(const BatchView& v) {
-    return v.tailList != nullptr && v.N <= 508;     // kFastHorizonLarge
+    return v.tailList != nullptr && v.wabs != nullptr && v.N <= 508;     // kFastHorizonLarge
 }
 inline size_t tail_lds_bytes(int N) {
     return (size_t)kTailPoints * (NZ * (N + 1) + NX * N + 32) * sizeof(real_t) + 256;
@@ -1411,7 +1411,7 @@ void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
     hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), step_lds_bytes(v.N), s, v, next_it);
 }
 bool line_search_tail_enabled(const BatchView& v) {
-    return v.tailList != nullptr && v.N <= kFastHorizonLarge;
+    return v.tailList != nullptr && v.wabs != nullptr && v.N <= kFastHorizonLarge;
 }
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     const dim3 grid_fast((v.nb + 3) / 4);
