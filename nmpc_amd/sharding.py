@@ -47,8 +47,15 @@ def gather_results(controls, status, iterations, group=None, counts=None):
     tail = rec.view(torch.int32)        # [m][8]: words 6 and 7 are the fourth double
     tail[:b, 6] = status
     tail[:b, 7] = iterations
-    full = torch.empty((world * m, 4), dtype=torch.float64, device=controls.device)
-    dist.all_gather_into_tensor(full, rec, group=group)
+    if dist.get_backend(group) == "gloo" and rec.is_cuda:
+        # gloo works on host memory: stage the records through it (rehearsals of the
+        # multi-rank path on fewer GPUs than ranks; RCCL gathers device to device)
+        host = torch.empty((world * m, 4), dtype=torch.float64)
+        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+        full = host.to(controls.device)
+    else:
+        full = torch.empty((world * m, 4), dtype=torch.float64, device=controls.device)
+        dist.all_gather_into_tensor(full, rec, group=group)
     if any(c != m for c in counts):
         full = torch.cat([full[r * m:r * m + c] for r, c in enumerate(counts)], dim=0)
     words = full.view(torch.int32)
