@@ -98,6 +98,19 @@ BOUND = {"linearise": "fp64-vector", "newton_solve": "issue-latency", "qp_begin"
          "newton_step": "hbm"}
 
 
+
+def same_bits(a, b):
+    """Same shape and, element for element, the same bit pattern (-0.0 is not +0.0);
+    two NaNs count as equal (x86 and gfx950 default NaNs differ in sign)."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype.kind != "f" or a.dtype != b.dtype:
+        return bool(np.array_equal(a, b))
+    bits = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return bool(np.all((a.view(bits) == b.view(bits)) | (np.isnan(a) & np.isnan(b))))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,7 +391,7 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
                 d["meas"][:n, 0], d["wind"][:n], threads=cores, precision=REAL["precision"])
             secs += s1
             passes += 1
-        parity = bool(np.array_equal(cu, u[:n]) and np.array_equal(cst, st[:n])
+        parity = bool(same_bits(cu, u[:n]) and np.array_equal(cst, st[:n])
                       and np.array_equal(cit, it[:n]))
         cpu = dict(value=round(n * passes / secs, 1), unit="solves/s", cores=cores, kind="port",
                    sample="first %d instances of the same workload, cold solve each, %d passes, "
@@ -486,7 +499,7 @@ def run_samples(a, world, rank, local, dev, dist, peaks):
                    kind="port",
                    sample="first %d samples of the same workload, %d passes, %.2f s wall on %d "
                           "threads" % (m, passes, secs, cores),
-                   gpu_results_identical=bool(np.array_equal(cj, gj) and np.array_equal(cr, gr)))
+                   gpu_results_identical=bool(same_bits(cj, gj) and same_bits(cr, gr)))
     if rank != 0:
         return None
     return {
@@ -572,7 +585,7 @@ def run_single(a, local, dev, peaks):
             drv.set_reference(refs[i], i)
         drv.feedback(meas[0])
         cu0, _ = drv.controls()
-        clat, same = [], bool(np.array_equal(np.asarray(cu0), np.asarray(u0)))
+        clat, same = [], same_bits(np.asarray(cu0, np.float64), np.asarray(u0, np.float64))
         for k in range(a.warmup + steps):
             t1 = time.perf_counter()
             drv.update_horizon(refs[N + 1 + k])
@@ -582,7 +595,7 @@ def run_single(a, local, dev, peaks):
             if k >= a.warmup:
                 clat.append((time.perf_counter() - t1) * 1e3)
                 j = k - a.warmup
-                same = same and bool(np.array_equal(np.asarray(cu), np.asarray(us[j]))
+                same = same and bool(same_bits(np.asarray(cu, np.float64), np.asarray(us[j], np.float64))
                                      and cst == sts[j])
         clat.sort()
         cpu = dict(value=round(1e3 * len(clat) / sum(clat), 1), unit="solves/s", cores=1, kind=kind,

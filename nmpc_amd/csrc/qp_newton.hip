@@ -47,8 +47,10 @@ NMPC_DEV real_t group_min(real_t x) {
 // q0 = RN(n y) is a faithful quotient, the residual is exact in an FMA, and the
 // corrected value rounds to RN(n / d)).  The faithfulness argument excludes
 // divisors whose significand is all ones; blocks that hold one use plain
-// division.  Checked against n / d on 2.6e10 random and adversarial operand
-// pairs on gfx950 (tools/micro_div.hip): no difference.
+// division.  Checked against n / d on 3.4e10 random, adversarial and exact
+// (zero numerators of either sign among them) operand pairs on gfx950
+// (tools/micro_div.hip): no difference.  Divisors are positive here (square
+// roots); over a negative one a zero quotient would keep the numerator's sign.
 NMPC_DEV bool plain_division_needed(real_t d) {
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: the substitutions divide plainly too
     return true;
@@ -60,9 +62,12 @@ NMPC_DEV bool plain_division_needed(real_t d) {
 template <bool FAST>
 NMPC_DEV real_t divide(real_t n, const Pivot& p) {
     if (!FAST) return n / p.d;
+    // The residual is taken with its sign turned: a residual of exactly zero comes
+    // out of the FMA as +0 and enters the correction as -0, which leaves q0 and
+    // the sign of a zero quotient as they are ((-0) / d is -0).
     const real_t q0 = n * p.y;
-    const real_t r = __builtin_fma(-p.d, q0, n);
-    return __builtin_fma(r, p.y, q0);
+    const real_t rn = __builtin_fma(p.d, q0, -n);
+    return __builtin_fma(-rn, p.y, q0);
 }
 
 // Column JJ of block row k of the reverse Cholesky (dual_qp.c:832-903): pivot,

@@ -98,12 +98,24 @@ def drive_gpu_batch(gs, dump=False):
     return out
 
 
+def same_bits(a, b):
+    """Element-wise: the same bit pattern (so -0.0 differs from +0.0), or both NaN
+    (x86 and gfx950 produce default NaNs of opposite sign)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind != "f" or b.dtype != a.dtype:
+        return a == b
+    bits = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return (a.view(bits) == b.view(bits)) | (np.isnan(a) & np.isnan(b))
+
+
 def assert_same(a, b, what):
     """Bit-for-bit equality with a readable first difference."""
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
-    if not np.array_equal(a, b):
-        d = np.argwhere(a != b)
+    ok = same_bits(a, b)
+    if not np.all(ok):
+        d = np.argwhere(~ok)
         i = tuple(d[0])
         raise AssertionError("%s: %d of %d entries differ, first at %s: %r vs %r" % (
             what, len(d), a.size, i, a[i], b[i]))

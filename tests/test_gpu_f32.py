@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
-from helpers import SEQUENCES_F32, assert_same, drive_gpu_batch, golden
+from helpers import SEQUENCES_F32, assert_same, same_bits, drive_gpu_batch, golden
 from nmpc_amd import _lib
 from nmpc_amd.batch import Batch, linearise_samples, rk4_samples
 lib = _lib.load()
@@ -75,7 +75,7 @@ for N, B, steps, seed in ((100, 300, 3, 808), (150, 24, 2, 809)):
         for b, p in enumerate(ports):
             p.feedback(d["meas"][b, k])
             eu, es = p.controls()
-            assert np.array_equal(u[b], eu) and st[b] == es and it[b] == p.num_iter(), (N, k, b, u[b], eu, st[b], es, it[b], p.num_iter())
+            assert same_bits(u[b], eu).all() and st[b] == es and it[b] == p.num_iter(), (N, k, b, u[b], eu, st[b], es, it[b], p.num_iter())
             p.update_horizon(d["refs"][b, N + 1 + k])
         converged += int((st == 0).sum())
         bt.update_horizon(d["refs"][:, N + 1 + k])

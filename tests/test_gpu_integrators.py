@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r); sys.path.insert(0, %(oracle)r)
-from helpers import assert_same
+from helpers import assert_same, same_bits
 from nmpc_amd import _lib
 from nmpc_amd import synthetic as S
 from nmpc_amd.batch import Batch, linearise_samples, rk4_samples
@@ -59,7 +59,7 @@ for k in range(steps):
     for b, p in enumerate(ports):
         p.feedback(d["meas"][b, k])
         eu, es = p.controls()
-        assert np.array_equal(uu[b], eu) and st[b] == es and it[b] == p.num_iter(), (k, b)
+        assert same_bits(uu[b], eu).all() and st[b] == es and it[b] == p.num_iter(), (k, b)
         p.update_horizon(d["refs"][b, N + 1 + k])
     good += int((st == 0).sum())
     bt.update_horizon(d["refs"][:, N + 1 + k])

@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import SEQUENCES, assert_same, config_of, drive_gpu_batch, golden
+from helpers import SEQUENCES, assert_same, same_bits, config_of, drive_gpu_batch, golden
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -88,7 +88,7 @@ def test_reference_interface_in_fresh_process():
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
-from helpers import golden
+from helpers import golden, same_bits
 import nmpc_amd as nmpc
 g = golden("seq_straight")
 nmpc.init()
@@ -106,7 +106,7 @@ for k in range(len(g["u"])):
     u, st = nmpc.get_result()
     assert nmpc.get_controls() == u
     assert st == g["status"][k], (k, st)
-    assert np.array_equal(np.array(u), g["u"][k]), (k, u, g["u"][k])
+    assert same_bits(np.array(u), g["u"][k]).all(), (k, u, g["u"][k])
     nmpc.update_horizon(list(g["refs"][101 + k]))
 # plant integration (c/cnmpc.cpp:173-180) against the golden RK4 vectors
 m = golden("model")
@@ -121,7 +121,7 @@ for i in range(5):
     # against an RK4 step of exactly that length
     from nmpc_amd.batch import rk4_samples
     exp = rk4_samples(m["x"][i:i+1], m["u"][i:i+1], m["wind"][i:i+1], delta=float(np.float32(0.02)))[0]
-    assert np.array_equal(got, exp), (i, got, exp)
+    assert same_bits(got, exp).all(), (i, got, exp)
 print("child ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)

@@ -17,7 +17,7 @@ from nmpc_amd.batch import Batch, linearise_samples, rk4_samples  # noqa: E402
 
 
 def report(name, a, b):
-    same = np.array_equal(a, b)
+    same = a.shape == b.shape and a.tobytes() == b.tobytes()
     if not same:
         d = np.argwhere(a != b)
         rel = np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
@@ -85,7 +85,7 @@ def check_sequence(B=8, N=100, steps=6, seed=5, full=True, turn=(0.3, 3.0)):
         for b in range(B):
             ports[b].feedback(meas[b, k])
             eu, est = ports[b].controls()
-            same = np.array_equal(u[b], eu) and st[b] == est and it[b] == ports[b].num_iter()
+            same = np.asarray(u[b]).tobytes() == np.asarray(eu, np.asarray(u[b]).dtype).tobytes() and st[b] == est and it[b] == ports[b].num_iter()
             if not same:
                 print("step %d inst %d: gpu u=%s st=%d it=%d | cpu u=%s st=%d it=%d info=%s" % (
                     k, b, u[b], st[b], it[b], eu, est, ports[b].num_iter(), bt.solver_info(b)))

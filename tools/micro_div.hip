@@ -5,6 +5,9 @@
 // rounded reciprocal y can be prepared off the critical path and the quotient
 // finished with three dependent instructions (Markstein):
 //     q0 = RN(n * y);  r = fma(-d, q0, n) (exact);  q = fma(r, y, q0)
+// taken as  rn = fma(d, q0, -n);  q = fma(-rn, y, q0): a residual of exactly zero
+// is then +0 where it is made and -0 where it is used, so that an exact quotient,
+// a zero one with its sign included, passes through unchanged.
 // This program measures both chains and counts results that differ from n / d
 // over random and adversarial operands.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o micro_div micro_div.hip
@@ -16,8 +19,8 @@
 
 __device__ __forceinline__ double fast_div(double n, double d, double y) {
     const double q0 = n * y;
-    const double r = __builtin_fma(-d, q0, n);
-    return __builtin_fma(r, y, q0);
+    const double rn = __builtin_fma(d, q0, -n);
+    return __builtin_fma(-rn, y, q0);
 }
 
 __device__ __forceinline__ uint64_t mix(uint64_t x) {
@@ -28,6 +31,9 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) {
 // mode 0: random significands, exponents within +-40 of zero
 // mode 1: divisor significand with a run of trailing ones / all ones
 // mode 2: numerator = RN(q * d) +- few ulps for a random q (quotients next to a rounding boundary)
+// mode 3: exact quotients: numerator +0, -0, or a small integer times a divisor of 26 bits;
+//         positive divisors only, as in the solver (its divisors are square roots): a zero
+//         over a negative divisor comes out with the sign of the numerator
 __global__ void check(uint64_t seed, int mode, int per_thread, unsigned long long* bad,
                       unsigned long long* bad_guarded, double* sample) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,6 +58,13 @@ __global__ void check(uint64_t seed, int mode, int per_thread, unsigned long lon
             const double prod = q * d;
             const long long k = (long long)(c % 7) - 3;
             n = __longlong_as_double(__double_as_longlong(prod) + k);
+        }
+        if (mode == 3) {
+            d = __longlong_as_double(__double_as_longlong(d) & 0x7ffffffff8000000LL);
+            const long long k = (long long)(c % 65) - 32;
+            n = (double)k * d;
+            if (c % 5 == 0) n = 0.0;
+            if (c % 5 == 1) n = -0.0;
         }
         const double y = 1.0 / d;
         const double ref = n / d;
@@ -84,7 +97,7 @@ int main() {
     unsigned long long *bad, *badg;
     double* sample;
     hipMalloc(&bad, 8); hipMalloc(&badg, 8); hipMalloc(&sample, 16);
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 4; mode++) {
         hipMemset(bad, 0, 8); hipMemset(badg, 0, 8);
         const int blocks = 1 << 14, threads = 256, per = 1 << 11;   // 2^33 pairs per mode
         check<<<blocks, threads>>>(0x1234567ULL + mode, mode, per, bad, badg, sample);

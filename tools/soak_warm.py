@@ -8,9 +8,12 @@ import numpy as np
 import portdriver as P
 from nmpc_amd import synthetic as S
 from nmpc_amd.batch import Batch
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import same_bits
 
 PREC = os.environ.get("SOAK_PRECISION", "double")     # float: with NMPC_AMD_LIB=.../libcnmpc_f32.so
 BOUNDS = os.environ.get("SOAK_TIGHT_BOUNDS")           # narrow control bounds: many active constraints
+DUMPS = int(os.environ.get("SOAK_DUMPS", "0"))         # compare the final state dumps of this many instances
 args = [int(a) for a in sys.argv[1:]]
 for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
     d = S.make_batch(B, N, extra_steps=steps, seed=seed)
@@ -22,6 +25,7 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
     got = []
     for k in range(steps):
         bt.solve(d["meas"][:, k]); got.append(bt.get_controls()); bt.update_horizon(d["refs"][:, N + 1 + k])
+    dumps = [(bt.stages(b), bt.globals_(b)) for b in range(min(DUMPS, B))]
     bt.close()
 
     def one(b):
@@ -35,11 +39,15 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
         for k in range(steps):
             p.feedback(d["meas"][b, k]); u, st = p.controls(); out.append((u, st, p.num_iter()))
             p.update_horizon(d["refs"][b, N + 1 + k])
+        if b < len(dumps):
+            out.append(int((~same_bits(dumps[b][0], p.stages())).sum() + (~same_bits(dumps[b][1], p.globals_())).sum()))
         return out
     with ThreadPoolExecutor(16) as pool:
         exp = list(pool.map(one, range(B)))
     bad = [(b, k) for b in range(B) for k in range(steps)
-           if not (np.array_equal(got[k][0][b], exp[b][k][0]) and got[k][1][b] == exp[b][k][1]
+           if not (same_bits(got[k][0][b], exp[b][k][0]).all() and got[k][1][b] == exp[b][k][1]
                    and got[k][2][b] == exp[b][k][2])]
     ok = sum(int((g[1] == 0).sum()) for g in got)
-    print(PREC, "tight" if BOUNDS else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5], flush=True)
+    dumped = [exp[b][steps] for b in range(len(dumps))]
+    print(PREC, "tight" if BOUNDS else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5],
+          "; state dumps of %d instances: %d entries differ" % (len(dumps), sum(dumped)) if dumps else "", flush=True)
