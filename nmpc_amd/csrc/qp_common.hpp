@@ -164,6 +164,15 @@ NMPC_DEV real_t stage_value(const real_t* H, const real_t* z, const real_t* q,
 // 16-byte loads and one 8-byte load, which halves the number of cache-line
 // look-ups of a wavefront whose lanes each read their own row.
 typedef real_t pair_u __attribute__((ext_vector_type(2), aligned(sizeof(real_t))));
+// Naturally aligned pair: the two gaps of a stage variable (y is [variable][2]
+// from a 256-byte aligned base), two consecutive entries of a Hessian block row.
+typedef real_t pair_a __attribute__((ext_vector_type(2)));
+NMPC_DEV void store_pair(real_t* p, real_t a, real_t b) {
+    pair_a v;
+    v.x = a;
+    v.y = b;
+    *(pair_a*)p = v;
+}
 NMPC_DEV void load_row15(const real_t* row, real_t (&out)[NZ]) {
 #pragma unroll
     for (int j = 0; j + 1 < NZ; j += 2) {

@@ -231,8 +231,7 @@ NMPC_DEV real_t stage_pass(const BatchView& v, const Inst& I, real_t a, const St
             if (MODE == kBegin || MODE == kCommit) I.zUnc[e] = zu;
             real_t y0, y1;
             const real_t zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
-            I.y[2 * e] = y0;
-            I.y[2 * e + 1] = y1;
+            store_pair(I.y + 2 * e, y0, y1);
             if (MODE == kTrialPoint) {
                 I.tmp[e] = zc;
             } else {
@@ -332,13 +331,17 @@ NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& 
 }
 
 // Newton Hessian block rows of the stages whose active set changed, every
-// WAVES-th block row per wavefront; slices: 360 doubles of LDS per wavefront.
+// WAVES-th block row per wavefront; slices: kSliceDoubles of LDS per wavefront:
+// C_k' P_k, then C_k, whose place (and 108 entries more) the finished block row
+// takes before it leaves.
+constexpr int kSliceDoubles = NX * NZ + 2 * NX * NX;
+static_assert((kStageThreads / kWave) * kSliceDoubles <= kBufDoubles, "slices live in buf");
 template <int WAVES>
 NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices) {
     const int tid = threadIdx.x, N = v.N;
     const int w = tid >> 6, lane = tid & 63;
-    real_t* Cs = slices + w * (2 * NX * NZ);
-    real_t* Zs = Cs + NX * NZ;
+    real_t* Zs = slices + w * kSliceDoubles;
+    real_t* Cs = Zs + NX * NZ;
     // The Jacobian entries and gaps of the next block row to assemble are fetched
     // while the current one is worked on.
     struct Fetched { real_t c[3], y[4]; };
@@ -352,10 +355,10 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
             f.c[t] = (e < NX * NZ) ? Cg[e] : 0.;
         }
         const int ly = lane < NZ ? lane : 0, lx = lane < NX ? lane : 0;
-        f.y[0] = I.y[2 * s * NZ + 2 * ly];
-        f.y[1] = I.y[2 * s * NZ + 2 * ly + 1];
-        f.y[2] = I.y[2 * sn * NZ + 2 * lx];
-        f.y[3] = I.y[2 * sn * NZ + 2 * lx + 1];
+        const pair_a yk = *(const pair_a*)(I.y + 2 * s * NZ + 2 * ly);
+        const pair_a yn = *(const pair_a*)(I.y + 2 * sn * NZ + 2 * lx);
+        f.y[0] = yk.x; f.y[1] = yk.y;
+        f.y[2] = yn.x; f.y[3] = yn.y;
     };
     int k = w;
     while (k < N && !needed(k)) k += WAVES;
@@ -387,12 +390,12 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // diagonal block: E P_{k+1} E' + C_k P_k C_k'
+        const bool wholeRow = k >= 1 && ck;             // the sub-diagonal block is written too
+        const int i = lane >> 2, j0 = (lane & 3) * 3;   // lanes 0..47: entries (i, j0..j0+2)
+        real_t m[3] = {0., 0., 0.};
         if (lane < 48) {
-            const int i = lane >> 2, j0 = (lane & 3) * 3;
-            real_t m[3];
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                m[t] = 0.;
                 if (i == j0 + t) {
                     m[t] = 1. / Hn[i];
                     if ((fixMask >> i) & 1ull) m[t] = 0.;
@@ -404,17 +407,41 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
 #pragma unroll
                 for (int t = 0; t < 3; t++) m[t] += ci * Zs[l * NX + j0 + t];
             }
-            real_t* Hd = I.hess + (size_t)k * 2 * NX * NX + i * 2 * NX + NX + j0;
-#pragma unroll
-            for (int t = 0; t < 3; t++) Hd[t] = m[t];
         }
-        // sub-diagonal block: -C_k[:, :12] P_k
-        if (k >= 1 && ck) {
-            for (int e = lane; e < NX * NX; e += kWave) {
-                const int i = e / NX, j = e % NX;
-                const real_t val = Cs[i * NZ + j] / v.H[j];
-                I.hess[(size_t)k * 2 * NX * NX + i * 2 * NX + j] =
-                    ((freeMask >> j) & 1ull) ? -val : 0.;
+        if (!wholeRow) {
+            if (lane < 48) {
+                real_t* Hd = I.hess + (size_t)k * 2 * NX * NX + i * 2 * NX + NX + j0;
+#pragma unroll
+                for (int t = 0; t < 3; t++) Hd[t] = m[t];
+            }
+        } else {
+            // The block row leaves as whole 16-byte pieces of consecutive addresses:
+            // it is put together where C_k was (a wavefront's LDS accesses are
+            // served in program order, so the reads above come first).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            real_t* row = Cs;
+            if (lane < 48) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) row[i * 2 * NX + NX + j0 + t] = m[t];
+            }
+            // sub-diagonal block: -C_k[:, :12] P_k, the quotients staged above
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int e = lane + t * kWave;
+                const int si = e / NX, sj = e % NX;
+                if (e < NX * NX)
+                    row[si * 2 * NX + sj] = ((freeMask >> sj) & 1ull) ? -Zs[sj * NX + si] : 0.;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            pair_a* out = (pair_a*)(I.hess + (size_t)k * 2 * NX * NX);
+            const pair_a* in = (const pair_a*)row;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int e = lane + t * kWave;
+                if (e < NX * NX) out[e] = in[e];
             }
         }
         // reads done before the next block row overwrites the slice
@@ -539,7 +566,8 @@ NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, real_t a, con
     for (int e = tid; e < eEnd; e += kStageThreads) {
         I.zUnc[e] = I.zUnc[e] + a * I.dz[e];
         I.q[e] = I.q[e] + a * I.qStep[e];
-        const real_t y0 = I.y[2 * e], y1 = I.y[2 * e + 1];
+        const pair_a yy = *(const pair_a*)(I.y + 2 * e);
+        const real_t y0 = yy.x, y1 = yy.y;
         const int s = e / NZ, i = e - s * NZ;
         const int idx = slot_position(v, s) * NZ + i;
         const int8_t code = (y0 > kEqTol) ? -1 : ((y1 > kEqTol) ? 1 : 0);
@@ -635,16 +663,16 @@ NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I
             const real_t d = qs / (k < N ? v.H[j] : v.Ht[j]);
             const real_t dzv = -d;
             I.dz[e] = dzv;
-            const real_t r0 = dzv / I.y[2 * e];
-            const real_t r1 = dzv / -I.y[2 * e + 1];
+            const pair_a yy = *(const pair_a*)(I.y + 2 * e);
+            const real_t r0 = dzv / yy.x;
+            const real_t r1 = dzv / -yy.y;
             const real_t aa = 1. / ((r0 > r1) ? r0 : r1);
             if (aa > 0. && aa < amin) amin = aa;
             // value trial at the full step
             const real_t zu = I.zUnc[e] + a * dzv;
             real_t y0, y1;
             const real_t zc = clip_gap(zu, I.zLow[e], I.zUpp[e], &y0, &y1);
-            I.y[2 * e] = y0;
-            I.y[2 * e + 1] = y1;
+            store_pair(I.y + 2 * e, y0, y1);
             I.z[e] = zc;
             L.z[idx] = zc;
             L.q[idx] = I.q[e] + a * qs;
@@ -1440,7 +1468,7 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
                        stage_lds_bytes(v.N), s, v, next_it);
     if (next_it <= kMaxIter)
         hipLaunchKernelGGL(k_line_search_hessian, dim3(grid_hessian), dim3(kTailThreads),
-                           (kTailThreads / kWave) * 2 * NX * NZ * sizeof(real_t), s, v, next_it);
+                           (kTailThreads / kWave) * kSliceDoubles * sizeof(real_t), s, v, next_it);
 }
 
 }  // namespace nmpc
