@@ -44,11 +44,14 @@ namespace nmpc {
 namespace {
 
 constexpr int kStageThreads = 256;
-// k_qp_begin waits on memory most of the time: seven resident wavefronts per
-// SIMD (72 registers per lane, no spills) measured 20 % faster than four; eight
-// spill.  k_newton_step needs about 120 registers; capping it lower spills and
-// is slower.
-#define NMPC_BEGIN_OCC __attribute__((amdgpu_waves_per_eu(7, 7)))
+// k_qp_begin waits on memory most of the time: six resident wavefronts per
+// SIMD (80 registers per lane, no spills) measured 7 % faster than seven (72
+// registers, a few spills) and 3 % faster than five.  k_newton_step needs about
+// 120 registers; capping it lower spills and is slower.
+#ifndef NMPC_BEGIN_WAVES
+#define NMPC_BEGIN_WAVES 6
+#endif
+#define NMPC_BEGIN_OCC __attribute__((amdgpu_waves_per_eu(NMPC_BEGIN_WAVES, NMPC_BEGIN_WAVES)))
 constexpr int kStageChunk = 64;                 // stage slots whose z, q sit in LDS at once
 constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920: z + q, reused as sum buffer
 
