@@ -45,8 +45,8 @@ namespace {
 
 constexpr int kStageThreads = 256;
 // k_qp_begin waits on memory most of the time: six resident wavefronts per
-// SIMD (80 registers per lane, no spills) measured 7 % faster than seven (72
-// registers, a few spills) and 3 % faster than five.  k_newton_step needs about
+// SIMD (80 registers per lane, eight of them spilled) measured 7 % faster than
+// seven and 9 % faster than five (96 registers, no spills).  k_newton_step needs about
 // 120 registers; capping it lower spills and is slower.
 #ifndef NMPC_BEGIN_WAVES
 #define NMPC_BEGIN_WAVES 6
@@ -339,7 +339,11 @@ NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& 
 // takes before it leaves.
 constexpr int kSliceDoubles = NX * NZ + 2 * NX * NX;
 static_assert((kStageThreads / kWave) * kSliceDoubles <= kBufDoubles, "slices live in buf");
-template <int WAVES>
+// WITH_GRADIENT: every block row is assembled (the caller has marked every
+// stage changed), and the twelve rows of the dual gradient that belong to a
+// block row (gradient_row's expression, term for term) are made from the
+// Jacobian while it is in LDS, which saves reading it a second time.
+template <int WAVES, bool WITH_GRADIENT = false>
 NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices) {
     const int tid = threadIdx.x, N = v.N;
     const int w = tid >> 6, lane = tid & 63;
@@ -348,7 +352,9 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
     // The Jacobian entries and gaps of the next block row to assemble are fetched
     // while the current one is worked on.
     struct Fetched { real_t c[3], y[4]; };
-    auto needed = [&](int k) { return k < N && (I.chg[k] != 0 || I.chg[k + 1] != 0); };
+    auto needed = [&](int k) {
+        return k < N && (WITH_GRADIENT || I.chg[k] != 0 || I.chg[k + 1] != 0);
+    };
     auto fetch = [&](int k, Fetched& f) {
         const int s = stage_slot(v, k), sn = stage_slot(v, k + 1);
         const real_t* Cg = I.C + (size_t)s * (NX * NZ);
@@ -388,10 +394,22 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
                 Zs[l * NX + i] = cur.c[t] / v.H[l];
             }
         }
+        real_t* zs = Cs + NX * NZ;                      // free until the finished row is put together
+        if (WITH_GRADIENT && lane < NZ) zs[lane] = I.z[stage_slot(v, k) * NZ + lane];
         // this wavefront's LDS writes land before its reads below
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (WITH_GRADIENT && lane < NX) {
+            const real_t ck = I.c[stage_slot(v, k) * NX + lane];
+            const real_t zn = I.z[stage_slot(v, k + 1) * NZ + lane];
+            real_t a = 0.;
+#pragma unroll 5
+            for (int j = 0; j < NZ; j++) a += Cs[lane * NZ + j] * zs[j];
+            a += ck;
+            a -= zn;
+            I.grad[k * NX + lane] = a;
+        }
         // diagonal block: E P_{k+1} E' + C_k P_k C_k'
         const bool wholeRow = k >= 1 && ck;             // the sub-diagonal block is written too
         const int i = lane >> 2, j0 = (lane & 3) * 3;   // lanes 0..47: entries (i, j0..j0+2)
@@ -803,7 +821,21 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
         I.sc->lsDeferred = 0;
     }
     __syncthreads();
-    newton_setup(v, I, L, 1);
+    // The first Newton set-up assembles every block row.  The convergence test
+    // (dual_qp.c:423-446) asks whether the root of the sum of the squared
+    // gradient rows is below the tolerance; the sum is at least each of its
+    // terms, so one row beyond twice the tolerance settles it without the sum,
+    // and gradient and Hessian then come out of one pass over the Jacobians.
+    // Otherwise: gradient, ordered sum, test, Hessian, as in later iterations.
+    const int probe = NX * v.N < 4 * NX ? NX * v.N : 4 * NX;
+    bool beyond = false;
+    if (tid < probe) beyond = fabs(gradient_row(v, I, I.z, tid)) > 2 * kStatTol;
+    if (__syncthreads_or(beyond)) {
+        if (tid == 0) I.sc->numIter = 1;
+        assemble_hessian<kStageThreads / kWave, true>(v, I, L.buf);
+    } else {
+        newton_setup(v, I, L, 1);
+    }
 }
 
 // ------------------------------------------------------------------------
