@@ -987,6 +987,16 @@ NMPC_DEV bool clips(real_t val, real_t lo, real_t up) {
     return (lo - val >= -kActTol) || (val - up >= -kActTol);
 }
 
+// In single precision the regrouped sum settles nothing: the row-ordered sum of
+// 24-bit terms is rounding noise itself near the root of the slope (its error
+// bound, some 1e-4 of the terms' magnitudes, exceeds the slopes a search ends
+// with), so only the same additions in the same order reproduce its sign.  That
+// build skips the first attempt, and the row-ordered kernels take the searches
+// from the list k_newton_step filled (counters 0.., entries 0..) instead of the
+// list of those left open (counters 8.., entries B..).
+constexpr bool kFirstAttempt = kDoublePrecision;
+constexpr int kOpenList = kFirstAttempt ? 8 : 0;
+
 // kFastSlots bounded variables per lane in registers: 6 for horizons up to 124 (four
 // searches per 256-lane workgroup); 0 = in LDS instead, for horizons up to 508 (one
 // search per 64-lane workgroup, 60 KB).
@@ -1210,9 +1220,9 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
     // gradient rows: thread t < 6 N owns rows h and h + 6 of block t / 6
     const int rk = tid / (NX / 2), rh = tid % (NX / 2);
     const bool rowOn = rk < N;
-    const int count = v.tailCount[8 + nextIt - 2];          // the searches k_line_search_fast left open
+    const int count = v.tailCount[kOpenList + nextIt - 2];  // the searches k_line_search_fast left open
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        const int b = v.tailList[v.B + item];
+        const int b = v.tailList[(kOpenList ? v.B : 0) + item];
         Inst I = instance(v, b);
         Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
         const real_t normal = I.sc->lsNormal;
@@ -1389,9 +1399,9 @@ __global__ __launch_bounds__(kStageThreads) void k_line_search_exact(BatchView v
     extern __shared__ real_t lds_raw[];
     const StageLds L = carve(lds_raw, v.N);
     const int n = NX * v.N;
-    const int count = v.tailCount[8 + nextIt - 2];
+    const int count = v.tailCount[kOpenList + nextIt - 2];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        Inst I = instance(v, v.tailList[v.B + item]);
+        Inst I = instance(v, v.tailList[(kOpenList ? v.B : 0) + item]);
         Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
         const real_t normal = I.sc->lsNormal;
         settle(bs);
@@ -1478,7 +1488,9 @@ bool line_search_tail_enabled(const BatchView& v) {
 }
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     const dim3 grid_fast((v.nb + 3) / 4);
-    if (v.N <= kFastHorizonSmall)
+    if (!kFirstAttempt)
+        ;
+    else if (v.N <= kFastHorizonSmall)
         hipLaunchKernelGGL(k_line_search_fast<6>, grid_fast, dim3(256), 0, s, v, next_it);
     else
         hipLaunchKernelGGL(k_line_search_fast<0>, dim3(v.nb), dim3(kWave), 0, s, v, next_it);

@@ -75,7 +75,9 @@ def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
     """Control loop (feedback, controls, horizon shift) of a whole batch against the
     port, instance by instance: warm steps are where half of the instances go
     through the handed-over step-length searches (the regrouped first attempt and
-    the row-ordered continuation; at N = 500 their long-horizon forms)."""
+    the row-ordered continuation; at N = 500 their long-horizon forms).  Controls,
+    status and iteration count of every instance and step; the complete stage
+    records and solver state of the first instances after the last step."""
     from concurrent.futures import ThreadPoolExecutor
     import portdriver as P
     from nmpc_amd import synthetic as S
@@ -92,6 +94,8 @@ def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
         bt.solve(d["meas"][:, k])
         got.append(bt.get_controls())
         bt.update_horizon(d["refs"][:, N + 1 + k])
+    dumped = 24                                  # instances whose whole state is compared at the end
+    dumps = [(bt.stages(b), bt.globals_(b)) for b in range(dumped)]
     bt.close()
 
     def one(b):
@@ -108,6 +112,9 @@ def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
             u, st = p.controls()
             out.append((u, st, p.num_iter()))
             p.update_horizon(d["refs"][b, N + 1 + k])
+        if b < dumped:
+            assert_same(dumps[b][0], p.stages(), "stage records, instance %d" % b)
+            assert_same(dumps[b][1], p.globals_(), "solver state, instance %d" % b)
         return out
     with ThreadPoolExecutor(8) as pool:       # the port's calls release the interpreter lock
         exp = list(pool.map(one, range(B)))

@@ -10,10 +10,10 @@ from nmpc_amd.batch import Batch
 B, N, W = int(os.environ.get("TS_B", "4096")), int(os.environ.get("TS_N", "100")), int(os.environ.get("WARM", "4"))
 dev = torch.device("cuda:0")
 d = S.make_batch(B, N, extra_steps=W, seed=S.DEFAULT_SEED)
-refs = torch.from_numpy(np.ascontiguousarray(d["refs"])).to(dev)
-meas = torch.from_numpy(np.ascontiguousarray(d["meas"])).to(dev)
-wind = torch.from_numpy(d["wind"]).to(dev)
 bt = Batch(B, N, stream=torch.cuda.current_stream().cuda_stream)
+refs = torch.from_numpy(np.ascontiguousarray(d["refs"], bt.dtype)).to(dev)     # the library's precision
+meas = torch.from_numpy(np.ascontiguousarray(d["meas"], bt.dtype)).to(dev)
+wind = torch.from_numpy(np.ascontiguousarray(d["wind"], bt.dtype)).to(dev)
 bt.setup(**S.setup_args())
 bt.initialise_horizon(); bt.set_wind_velocity(wind); bt.set_reference(refs[:, :N + 1].contiguous())
 out = (C.c_int * 16)()
