@@ -208,7 +208,7 @@ def test_small_and_odd_shapes(port_built):
     from nmpc_amd import synthetic as S
     # 106 / 120: largest horizon the line-search hand-over kernels take / first one past it
     # (2, 5, 12) and (3, 70, 75): more horizon shifts than stages, every ring offset wraps
-    for B, N, steps in ((3, 7, 6), (1, 2, 4), (5, 65, 3), (4, 106, 3), (4, 120, 3), (2, 5, 12),
+    for B, N, steps in ((3, 7, 6), (1, 2, 4), (2, 3, 4), (5, 65, 3), (4, 106, 3), (4, 120, 3), (2, 5, 12),
                         (3, 70, 75)):
         d = S.make_batch(B, N, extra_steps=steps, seed=B * 100 + N, turn_start=(0.05, 0.5))
         gs = []
