@@ -94,8 +94,13 @@ ALGO = {
 # what limits each kernel: linearise sits at the fp64-vector / HBM ridge and is
 # instruction-bound; the Newton solve is a dependent chain per instance,
 # HBM-bound only while every block is factorised
-BOUND = {"linearise": "fp64-vector", "newton_solve": "issue-latency", "qp_begin": "hbm",
-         "newton_step": "hbm"}
+BOUND = {"linearise": "vector-alu", "newton_solve": "hbm", "qp_begin": "hbm", "newton_step": "hbm"}
+LIMITER = {
+    "linearise": "vector instruction issue (FMA contraction is off: the ceiling is the FMA-free rate)",
+    "newton_solve": "instruction issue of one wavefront per SIMD running one dependent chain per "
+                    "instance; HBM only in the launch that factorises every block",
+    "qp_begin": "HBM", "newton_step": "HBM",
+}
 
 
 
@@ -173,17 +178,21 @@ def make_roofline(kernel, kern, algo_bytes, peaks, traffic):
     achieved = k["algo_GBps"]
     r = dict(kernel=kernel, bound=BOUND.get(kernel, "hbm"), achieved=achieved, peak=HBM_PEAK_GBS,
              unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-             avg_launch_ms=k["avg_ms"],
+             limiter=LIMITER.get(kernel, "HBM"), avg_launch_ms=k["avg_ms"],
              algo_bytes_per_launch=round(algo_bytes[kernel] / max(1, k["launches"])),
              fp64_vector_TFLOPs=k["algo_TFLOPs"],
              fp64_vector_frac=round(k["algo_TFLOPs"] / REAL["peak_tf"], 5))
+    if r["bound"] == "vector-alu":  # priced against the vector arithmetic peak; bytes beside it
+        r.update(achieved=k["algo_TFLOPs"], peak=REAL["peak_tf"], unit="TFLOP/s",
+                 frac=round(k["algo_TFLOPs"] / REAL["peak_tf"], 5), hbm_GBps=achieved,
+                 hbm_frac=round(achieved / HBM_PEAK_GBS, 5))
     if REAL["name"] != "f64":       # the same two fields under the names that fit
         r["vector_TFLOPs"] = r.pop("fp64_vector_TFLOPs")
         r["%s_vector_frac" % REAL["name"]] = r.pop("fp64_vector_frac")
     if peaks:
         r["peak_measured"] = peaks
         if peaks.get("hbm_triad_GBps"):
-            r["frac_of_measured_hbm"] = round(achieved / peaks["hbm_triad_GBps"], 5)
+            r["frac_of_measured_hbm"] = round(k["algo_GBps"] / peaks["hbm_triad_GBps"], 5)
         if peaks.get("fp64_vector_no_fma_TFLOPs") and REAL["name"] == "f64":
             r["frac_of_measured_fp64_no_fma"] = round(
                 k["algo_TFLOPs"] / peaks["fp64_vector_no_fma_TFLOPs"], 5)
