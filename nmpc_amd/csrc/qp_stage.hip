@@ -884,6 +884,19 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
             if (nd * (alpha - (real_t)0.) < kEqTol) { alpha = 0.; st = ST_LS_MIN_STEP; break; }
         }
         if (st == ST_LS_MIN_STEP) {
+            if (haveSlope && keepGrad) {
+                // The solve ends here, and the reference's gradient record is still the
+                // one of this iteration's set-up, which the sweep above has replaced with
+                // the full step's: make it again from the committed point, clip(zUnc)
+                // (z and y stay the last value trial's, as in the reference).
+                const int eEnd = NZ * N + NX;
+                for (int e = tid; e < eEnd; e += kStageThreads) {
+                    real_t y0, y1;
+                    I.tmp[e] = clip_gap(I.zUnc[e], I.zLow[e], I.zUpp[e], &y0, &y1);
+                }
+                __syncthreads();
+                for (int r = tid; r < n; r += kStageThreads) I.grad[r] = gradient_row(v, I, I.tmp, r);
+            }
             if (tid == 0) {
                 I.sc->status = ST_NO_ASCENT;
                 I.sc->alpha = alpha;

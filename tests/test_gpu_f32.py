@@ -81,6 +81,38 @@ for N, B, steps, seed in ((100, 300, 3, 808), (150, 24, 2, 809)):
         bt.update_horizon(d["refs"][:, N + 1 + k])
     assert converged > B // 2, (N, converged)
     bt.close()
+
+# A step-length search that fails (no ascent direction: the solve ends there,
+# dual_qp.c:1294-1334) must leave the solver state the reference leaves, the
+# gradient record of the iteration's set-up included: instance 195 of this
+# seeded batch ends its sixth step that way.
+N, steps, first, count = 100, 6, 192, 8
+d = S.make_batch(4096, N, extra_steps=steps, seed=108)
+d = {k: v[first:first + count] for k, v in d.items()}
+cfg = S.setup_args()
+bt = Batch(count, N); bt.setup(**cfg); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
+bt.set_reference(d["refs"][:, :N + 1])
+for k in range(steps):
+    bt.solve(d["meas"][:, k]); u, st, it = bt.get_controls()
+    if k + 1 < steps:
+        bt.update_horizon(d["refs"][:, N + 1 + k])
+assert bt.solver_info(195 - first)["status"] == 13 and it[195 - first] < 5, bt.solver_info(195 - first)
+for b in range(count):
+    p = P.Port(N, "float")
+    p.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+            cfg["upper_control_bound"], cfg["lower_control_bound"])
+    p.init(); p.set_wind(d["wind"][b])
+    for i in range(N + 1):
+        p.set_reference(d["refs"][b, i], i)
+    for k in range(steps):
+        p.feedback(d["meas"][b, k])
+        if k + 1 < steps:
+            p.update_horizon(d["refs"][b, N + 1 + k])
+    eu, es = p.controls()
+    assert same_bits(u[b], eu).all() and st[b] == es and it[b] == p.num_iter(), b
+    assert_same(bt.stages(b), p.stages(), "stage records, instance %%d" %% (first + b))
+    assert_same(bt.globals_(b), p.globals_(), "solver state, instance %%d" %% (first + b))
+bt.close()
 print("child ok")
 """
 
