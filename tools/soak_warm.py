@@ -14,17 +14,24 @@ from helpers import same_bits
 PREC = os.environ.get("SOAK_PRECISION", "double")     # float: with NMPC_AMD_LIB=.../libcnmpc_f32.so
 BOUNDS = os.environ.get("SOAK_TIGHT_BOUNDS")           # narrow control bounds: many active constraints
 DUMPS = int(os.environ.get("SOAK_DUMPS", "0"))         # compare the final state dumps of this many instances
+RTI = os.environ.get("SOAK_RTI")                       # real-time-iteration preparation before every solve
+NOISE = float(os.environ.get("SOAK_NOISE", "1"))       # measurement deviations (position, velocity, rates) times this:
+                                                       # large values drive solves into their failure paths
 args = [int(a) for a in sys.argv[1:]]
 for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
     d = S.make_batch(B, N, extra_steps=steps, seed=seed)
     cfg = S.setup_args()
+    if NOISE != 1:
+        base = d["refs"][:, :steps + 1, :13]
+        for sl in (slice(0, 6), slice(10, 13)):
+            d["meas"][:, :, sl] = base[:, :, sl] + NOISE * (d["meas"][:, :, sl] - base[:, :, sl])
     if BOUNDS:
         cfg.update(upper_control_bound=[0.62, 0.55, 0.55], lower_control_bound=[0.4, 0.45, 0.45])
-    bt = Batch(B, N); bt.setup(**cfg); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
+    bt = Batch(B, N); bt.setup(**cfg); bt.set_rti(bool(RTI)); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
     bt.set_reference(d["refs"][:, :N + 1])
     got = []
     for k in range(steps):
-        bt.solve(d["meas"][:, k]); got.append(bt.get_controls()); bt.update_horizon(d["refs"][:, N + 1 + k])
+        bt.prepare(); bt.solve(d["meas"][:, k]); got.append(bt.get_controls()); bt.update_horizon(d["refs"][:, N + 1 + k])
     dumps = [(bt.stages(b), bt.globals_(b)) for b in range(min(DUMPS, B))]
     bt.close()
 
@@ -37,6 +44,8 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
             p.set_reference(d["refs"][b, i], i)
         out = []
         for k in range(steps):
+            if RTI:
+                p.prepare_rti()
             p.feedback(d["meas"][b, k]); u, st = p.controls(); out.append((u, st, p.num_iter()))
             p.update_horizon(d["refs"][b, N + 1 + k])
         if b < len(dumps):
@@ -49,5 +58,5 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
                    and got[k][2][b] == exp[b][k][2])]
     ok = sum(int((g[1] == 0).sum()) for g in got)
     dumped = [exp[b][steps] for b in range(len(dumps))]
-    print(PREC, "tight" if BOUNDS else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5],
+    print(PREC, "rti" if RTI else "", "tight" if BOUNDS else "", "noise x%g" % NOISE if NOISE != 1 else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5],
           "; state dumps of %d instances: %d entries differ" % (len(dumps), sum(dumped)) if dumps else "", flush=True)
