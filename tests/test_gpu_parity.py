@@ -233,6 +233,35 @@ def test_small_and_odd_shapes(port_built):
             assert_same(out["final_globals"][b], exp["final_globals"], tag + "solver state")
 
 
+def test_model_and_linearisation_on_hostile_inputs(port_built):
+    """Huge, tiny, zero, infinite and NaN entries in state, controls, wind and
+    successor: the integration and the stage linearisation give what the port
+    gives, entry for entry (a NaN for a NaN), also where the root-and-reciprocal
+    shortcut of the aircraft model has to stand aside."""
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import linearise_samples, rk4_samples
+    n = 3000
+    rng = np.random.default_rng(77)
+    x, u, w = S.random_states(n, rng, spread=3.0)
+    xn = np.roll(x, 1, axis=0).copy()
+    special = np.array([0.0, -0.0, 1e-310, -1e-300, 1e150, -1e200, 1e308, np.inf, -np.inf, np.nan,
+                        1.0, -1.0, 1e-20])
+    hit = rng.random(n) < 0.5
+    for arr in (x, u, w, xn):
+        m = (rng.random(arr.shape) < 0.08) & hit[:, None]
+        arr[m] = special[rng.integers(0, len(special), int(m.sum()))]
+    lo, up = np.zeros(3), np.ones(3)
+    xp = rk4_samples(x, u, w)
+    jac, res = linearise_samples(x, u, xn, w, lo, up)
+    assert (~np.isfinite(xp)).any(axis=1).sum() > n // 10           # the hostile part is there
+    for i in range(n):
+        assert_same(xp[i], np.asarray(P.rk4(x[i], u[i], w[i])), "x+ of sample %d" % i)
+        ej, er = P.linearise(x[i], u[i], xn[i], w[i], lo, up)
+        assert_same(jac[i].ravel(), np.asarray(ej).ravel(), "Jacobian of sample %d" % i)
+        assert_same(res[i], np.asarray(er), "residual of sample %d" % i)
+
+
 def test_million_sample_linearisation(port_built):
     """2^20 (x, u, wind) samples through the stage-linearisation kernel:
     a strided subset against the oracle and batch-position independence."""
