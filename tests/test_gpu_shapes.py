@@ -70,19 +70,18 @@ def test_bounds_changed_between_init_and_partial_reference_loading(port_built):
         assert (exp[6, 204:207] == 0.0).all() and (exp[1, 204:207] != 0.0).all()
 
 
-@pytest.mark.parametrize("B,N,steps,seed", [(1024, 100, 5, 4242), (96, 500, 3, 4343)])
-def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
+def batch_against_port(B, N, steps, seed, dumped, mutate=None):
     """Control loop (feedback, controls, horizon shift) of a whole batch against the
-    port, instance by instance: warm steps are where half of the instances go
-    through the handed-over step-length searches (the regrouped first attempt and
-    the row-ordered continuation; at N = 500 their long-horizon forms).  Controls,
-    status and iteration count of every instance and step; the complete stage
-    records and solver state of the first instances after the last step."""
+    port, instance by instance: controls, status and iteration count of every
+    instance and step; the complete stage records and solver state of the first
+    `dumped` instances after the last step.  Returns the number of converged solves."""
     from concurrent.futures import ThreadPoolExecutor
     import portdriver as P
     from nmpc_amd import synthetic as S
     from nmpc_amd.batch import Batch
     d = S.make_batch(B, N, extra_steps=steps, seed=seed)
+    if mutate:
+        mutate(d)
     cfg = S.setup_args()
     bt = Batch(B, N)
     bt.setup(**cfg)
@@ -94,7 +93,6 @@ def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
         bt.solve(d["meas"][:, k])
         got.append(bt.get_controls())
         bt.update_horizon(d["refs"][:, N + 1 + k])
-    dumped = 24                                  # instances whose whole state is compared at the end
     dumps = [(bt.stages(b), bt.globals_(b)) for b in range(dumped)]
     bt.close()
 
@@ -122,4 +120,31 @@ def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
            if not (same_bits(got[k][0][b], exp[b][k][0]).all() and got[k][1][b] == exp[b][k][1]
                    and got[k][2][b] == exp[b][k][2])]
     assert not bad, bad[:10]
-    assert sum(int((g[1] == 0).sum()) for g in got) > B * steps // 4      # the comparison is not vacuous
+    return sum(int((g[1] == 0).sum()) for g in got)
+
+
+@pytest.mark.parametrize("B,N,steps,seed", [(1024, 100, 5, 4242), (96, 500, 3, 4343)])
+def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
+    """Warm steps are where half of the instances go through the handed-over
+    step-length searches (the regrouped first attempt and the row-ordered
+    continuation; at N = 500 their long-horizon forms)."""
+    converged = batch_against_port(B, N, steps, seed, dumped=24)
+    assert converged > B * steps // 4        # the comparison is not vacuous
+
+
+def test_hostile_inputs_through_the_solver(port_built):
+    """Zero, huge, infinite and NaN entries in the measurements, the wind and the
+    reference points of four instances in ten: every kernel ends, and controls,
+    status, iteration counts and the complete end state are the port's (a NaN
+    for a NaN)."""
+    def mutate(d):
+        rng = np.random.default_rng(99)
+        special = np.array([0.0, -0.0, 1e-300, 1e150, -1e200, np.inf, -np.inf, np.nan, 1e6, -1e4])
+        B = d["wind"].shape[0]
+        pick = rng.random(B) < 0.4
+        for key in ("meas", "wind", "refs"):
+            arr = d[key]
+            m = (rng.random(arr.shape) < 0.02) & pick.reshape((B,) + (1,) * (arr.ndim - 1))
+            arr[m] = special[rng.integers(0, len(special), int(m.sum()))]
+    converged = batch_against_port(160, 100, 3, 4444, dumped=160, mutate=mutate)
+    assert 160 * 3 * 3 // 4 > converged > 160 * 3 // 4      # some instances fail on their inputs, the others solve

@@ -15,6 +15,7 @@ PREC = os.environ.get("SOAK_PRECISION", "double")     # float: with NMPC_AMD_LIB
 BOUNDS = os.environ.get("SOAK_TIGHT_BOUNDS")           # narrow control bounds: many active constraints
 DUMPS = int(os.environ.get("SOAK_DUMPS", "0"))         # compare the final state dumps of this many instances
 RTI = os.environ.get("SOAK_RTI")                       # real-time-iteration preparation before every solve
+HOSTILE = float(os.environ.get("SOAK_HOSTILE", "0"))   # fraction of instances with non-finite / huge inputs
 NOISE = float(os.environ.get("SOAK_NOISE", "1"))       # measurement deviations (position, velocity, rates) times this:
                                                        # large values drive solves into their failure paths
 args = [int(a) for a in sys.argv[1:]]
@@ -25,6 +26,16 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
         base = d["refs"][:, :steps + 1, :13]
         for sl in (slice(0, 6), slice(10, 13)):
             d["meas"][:, :, sl] = base[:, :, sl] + NOISE * (d["meas"][:, :, sl] - base[:, :, sl])
+    if HOSTILE:
+        # zero, huge, infinite and NaN entries in the measurements, the wind and the
+        # reference points of some instances
+        hr = np.random.default_rng(seed + 1)
+        special = np.array([0.0, -0.0, 1e-300, 1e150, -1e200, np.inf, -np.inf, np.nan, 1e6, -1e4])
+        pick = hr.random(B) < HOSTILE
+        for key in ("meas", "wind", "refs"):
+            arr = d[key]
+            m = (hr.random(arr.shape) < 0.02) & pick.reshape((B,) + (1,) * (arr.ndim - 1))
+            arr[m] = special[hr.integers(0, len(special), int(m.sum()))]
     if BOUNDS:
         cfg.update(upper_control_bound=[0.62, 0.55, 0.55], lower_control_bound=[0.4, 0.45, 0.45])
     bt = Batch(B, N); bt.setup(**cfg); bt.set_rti(bool(RTI)); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"])
@@ -58,5 +69,5 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
                    and got[k][2][b] == exp[b][k][2])]
     ok = sum(int((g[1] == 0).sum()) for g in got)
     dumped = [exp[b][steps] for b in range(len(dumps))]
-    print(PREC, "rti" if RTI else "", "tight" if BOUNDS else "", "noise x%g" % NOISE if NOISE != 1 else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5],
+    print(PREC, "rti" if RTI else "", "tight" if BOUNDS else "", "noise x%g" % NOISE if NOISE != 1 else "", "hostile %g" % HOSTILE if HOSTILE else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5],
           "; state dumps of %d instances: %d entries differ" % (len(dumps), sum(dumped)) if dumps else "", flush=True)
