@@ -303,7 +303,9 @@ int nmpc_rk4_samples(int device, void *stream, uint64_t n, const real_t *x,
  * fused != 0 uses one fused multiply-add per step (2 flop), fused == 0 a
  * multiply and an add (the library's own kernels are built without
  * contraction).  Stream triad: a[i] = b[i] + s * c[i] over three arrays of
- * bytes_per_array each, 16 bytes per lane and access; reports 3 x bytes / time. */
+ * bytes_per_array each, 16 bytes per lane and access, in three launch shapes
+ * (eight and two workgroups per CU striding through the arrays, one workgroup
+ * per contiguous 64 KB); reports 3 x bytes / time of the fastest pass. */
 int nmpc_measure_fp64_vector_peak(int device, int fused, double *tflops);
 int nmpc_measure_stream_triad(int device, uint64_t bytes_per_array, double *gbps);
 

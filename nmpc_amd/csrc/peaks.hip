@@ -56,6 +56,23 @@ __global__ __launch_bounds__(256) void k_triad(pair_t* __restrict__ a, const pai
     }
 }
 
+// The same with one contiguous 64 KB piece of each array per workgroup.  Which of
+// the two shapes the memory system likes better varies from box to box and with
+// the number of resident wavefronts (4.1 to 6.1 TB/s over the shapes
+// tools/micro_hbm.hip tries); the measurement reports the best it sees.
+__global__ __launch_bounds__(256) void k_triad_pieces(pair_t* __restrict__ a, const pair_t* __restrict__ b,
+                                                      const pair_t* __restrict__ c, double s, size_t n2) {
+    const size_t per = 4096;            // pairs per workgroup: 64 KB
+    const size_t lo = per * blockIdx.x, hi = lo + per < n2 ? lo + per : n2;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const pair_t bv = b[i], cv = c[i];
+        pair_t r;
+        r.x = bv.x + s * cv.x;
+        r.y = bv.y + s * cv.y;
+        a[i] = r;
+    }
+}
+
 #define PK_TRY(expr)                                       \
     do {                                                   \
         hipError_t e_ = (expr);                            \
@@ -121,14 +138,21 @@ int nmpc_measure_stream_triad(int device, uint64_t bytes_per_array, double* gbps
     PK_TRY(hipMemset(c, 0, n2 * sizeof(pair_t)));
     PK_TRY(hipEventCreate(&e0));
     PK_TRY(hipEventCreate(&e1));
-    for (int pass = 0; pass < 5; pass++) {
+    for (int pass = 0; pass < 12; pass++) {     // four passes of each shape, the first of each untimed
+        const int shape = pass / 4;
         PK_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(k_triad, dim3(blocks), dim3(256), 0, nullptr, a, b, c, 3.0, n2);
+        if (shape == 0)
+            hipLaunchKernelGGL(k_triad, dim3(blocks), dim3(256), 0, nullptr, a, b, c, 3.0, n2);
+        else if (shape == 1)
+            hipLaunchKernelGGL(k_triad, dim3(blocks / 4), dim3(256), 0, nullptr, a, b, c, 3.0, n2);
+        else
+            hipLaunchKernelGGL(k_triad_pieces, dim3((unsigned)((n2 + 4095) / 4096)), dim3(256), 0, nullptr,
+                               a, b, c, 3.0, n2);
         PK_TRY(hipGetLastError());
         PK_TRY(hipEventRecord(e1, nullptr));
         PK_TRY(hipEventSynchronize(e1));
         PK_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (pass > 0 && ms < best) best = ms;
+        if (pass % 4 > 0 && ms < best) best = ms;
     }
     *gbps = 3.0 * (double)(n2 * sizeof(pair_t)) / (best * 1e-3) / 1e9;
 done:
