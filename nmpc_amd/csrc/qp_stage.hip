@@ -302,7 +302,7 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
 // Dual gradient and its norm (convergence test), then the Newton Hessian block
 // rows of every stage whose active set changed (dual_qp.c:423-597).  Each of
 // the four wavefronts assembles every fourth block row: it stages C_k and
-// C_k' P_k in its own slice of LDS, 48 lanes then own three entries of the
+// C_k P_k in its own slice of LDS, 48 lanes then own three entries of the
 // 12x12 diagonal block each and add the free columns' dyads in column order.
 // gradKept: grad already holds the gradient at z (a slope trial at the committed
 // step stored it).
@@ -335,7 +335,7 @@ NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& 
 
 // Newton Hessian block rows of the stages whose active set changed, every
 // WAVES-th block row per wavefront; slices: kSliceDoubles of LDS per wavefront:
-// C_k' P_k, then C_k, whose place (and 108 entries more) the finished block row
+// C_k P_k, then C_k, whose place (and 108 entries more) the finished block row
 // takes before it leaves.
 constexpr int kSliceDoubles = NX * NZ + 2 * NX * NX;
 static_assert((kStageThreads / kWave) * kSliceDoubles <= kBufDoubles, "slices live in buf");
@@ -384,14 +384,14 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
         const bool fx = lane < NX && (cur.y[2] >= kEqTol || cur.y[3] >= kEqTol);
         const unsigned long long freeMask = __ballot(fr);
         const unsigned long long fixMask = __ballot(fx);
-        // C_k and C_k' P_k (entry (i, l) of C goes to (l, i) of the product)
+        // C_k and C_k P_k, both laid out as C_k is: consecutive lanes write consecutive words
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int e = lane + t * kWave;
             if (e < NX * NZ) {
-                const int i = e / NZ, l = e % NZ;
+                const int l = e % NZ;
                 Cs[e] = cur.c[t];
-                Zs[l * NX + i] = cur.c[t] / v.H[l];
+                Zs[e] = cur.c[t] / v.H[l];
             }
         }
         real_t* zs = Cs + NX * NZ;                      // free until the finished row is put together
@@ -426,7 +426,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
                 if (!((freeMask >> l) & 1ull)) continue;
                 const real_t ci = Cs[i * NZ + l];
 #pragma unroll
-                for (int t = 0; t < 3; t++) m[t] += ci * Zs[l * NX + j0 + t];
+                for (int t = 0; t < 3; t++) m[t] += ci * Zs[(j0 + t) * NZ + l];
             }
         }
         if (!wholeRow) {
@@ -452,7 +452,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
                 const int e = lane + t * kWave;
                 const int si = e / NX, sj = e % NX;
                 if (e < NX * NX)
-                    row[si * 2 * NX + sj] = ((freeMask >> sj) & 1ull) ? -Zs[sj * NX + si] : 0.;
+                    row[si * 2 * NX + sj] = ((freeMask >> sj) & 1ull) ? -Zs[si * NZ + sj] : 0.;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
