@@ -1501,12 +1501,12 @@ bool line_search_tail_enabled(const BatchView& v) {
 }
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     const dim3 grid_fast((v.nb + 3) / 4);
-    if (!kFirstAttempt)
-        ;
-    else if (v.N <= kFastHorizonSmall)
-        hipLaunchKernelGGL(k_line_search_fast<6>, grid_fast, dim3(256), 0, s, v, next_it);
-    else
-        hipLaunchKernelGGL(k_line_search_fast<0>, dim3(v.nb), dim3(kWave), 0, s, v, next_it);
+    if (kFirstAttempt) {
+        if (v.N <= kFastHorizonSmall)
+            hipLaunchKernelGGL(k_line_search_fast<6>, grid_fast, dim3(256), 0, s, v, next_it);
+        else
+            hipLaunchKernelGGL(k_line_search_fast<0>, dim3(v.nb), dim3(kWave), 0, s, v, next_it);
+    }
     // what the first attempt left open
     if (v.N <= kTailMaxHorizon) {
         const int grid = v.nb < 256 ? v.nb : 256;
