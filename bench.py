@@ -223,8 +223,12 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     bt = Batch(B, N, device=local, stream=stream.cuda_stream)
     bt.setup(**S.setup_args())
 
+    gather = None
     if world > 1:
         from nmpc_amd import sharding
+        # results of every step go to every rank; the collective of one step runs
+        # beside the kernels of the next
+        gather = sharding.ResultGather([B] * world, dev)
 
     def step():
         bt.reset()
@@ -234,8 +238,8 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
         bt.prepare()
         bt.solve(meas)
         bt.get_controls_into(out_u, out_st, out_it)
-        if world > 1:
-            return sharding.gather_results(out_u, out_st, out_it, counts=[B] * world)
+        if gather:
+            gather.start(out_u, out_st, out_it)
         return out_u, out_st, out_it
 
     # Every timed launch costs two event packets on the stream, so the timed region
@@ -259,6 +263,8 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     for k in range(a.steps):
         res = step()
         marks[k + 1].record(stream)
+    if gather:
+        res = gather.finish()       # the last step's collective ends inside the timed region
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -277,6 +283,8 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
         bt.set_profiling(True)
         for _ in range(table_steps):
             step()
+        if gather:
+            gather.finish()
         ktable = bt.kernel_times()
         bt.set_profiling(False)
     torch.cuda.synchronize(dev)

@@ -60,3 +60,66 @@ def gather_results(controls, status, iterations, group=None, counts=None):
         full = torch.cat([full[r * m:r * m + c] for r, c in enumerate(counts)], dim=0)
     words = full.view(torch.int32)
     return (full[:, 0:3].contiguous(), words[:, 6].contiguous(), words[:, 7].contiguous())
+
+
+class ResultGather:
+    """The same gather for a control loop: buffers are allocated once, and the
+    collective of step k runs beside the kernels of step k+1 (the next step needs
+    nothing from it), so ranks do not wait for each other inside a step.
+
+        g = ResultGather(counts, device)
+        for every step:  ...solve...; g.start(controls, status, iterations)
+        u, st, it = g.finish()            # the results of the last step started
+
+    start() packs this rank's records and issues the all-gather without waiting
+    for it; two sets of buffers alternate, and a set is reused only after its
+    collective has completed.  finish() waits for the last collective."""
+
+    def __init__(self, counts, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.counts = [int(c) for c in counts]
+        self.group = group
+        self.world = dist.get_world_size(group)
+        assert len(self.counts) == self.world
+        self.m = max(self.counts)
+        self.device = torch.device(device)
+        self.staged = dist.get_backend(group) == "gloo" and self.device.type == "cuda"
+        side = torch.device("cpu") if self.staged else self.device
+        self.rec = [torch.zeros((self.m, 4), dtype=torch.float64, device=self.device) for _ in range(2)]
+        self.full = [torch.empty((self.world * self.m, 4), dtype=torch.float64, device=side) for _ in range(2)]
+        self.work = [None, None]
+        self.turn = 0
+        self.last = None
+
+    def start(self, controls, status, iterations):
+        import torch
+        import torch.distributed as dist
+
+        i = self.turn
+        self.turn ^= 1
+        if self.work[i] is not None:
+            self.work[i].wait()
+        rec = self.rec[i]
+        b = controls.shape[0]
+        rec[:b, 0:3] = controls
+        words = rec.view(torch.int32)       # [m][8]: words 6 and 7 are the fourth double
+        words[:b, 6] = status
+        words[:b, 7] = iterations
+        src = rec.cpu() if self.staged else rec
+        self.work[i] = dist.all_gather_into_tensor(self.full[i], src, group=self.group, async_op=True)
+        self.last = i
+
+    def finish(self):
+        import torch
+
+        assert self.last is not None, "start() has not been called"
+        i = self.last
+        self.work[i].wait()
+        self.work[i] = None
+        full = self.full[i].to(self.device)
+        if any(c != self.m for c in self.counts):
+            full = torch.cat([full[r * self.m:r * self.m + c] for r, c in enumerate(self.counts)], dim=0)
+        words = full.view(torch.int32)
+        return (full[:, 0:3].contiguous(), words[:, 6].contiguous(), words[:, 7].contiguous())

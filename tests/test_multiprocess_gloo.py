@@ -50,6 +50,12 @@ def _worker(rank, world, port, total, N, seed, out_dir):
     ku, ks, ki = sharding.gather_results(torch.from_numpy(u), torch.from_numpy(st),
                                          torch.from_numpy(it), counts=counts)
     assert torch.equal(ku, gu) and torch.equal(ks, gs) and torch.equal(ki, gi)
+    # the control-loop form: three steps in flight one after the other, buffers reused
+    g = sharding.ResultGather(counts, "cpu")
+    for k in range(3):
+        g.start(torch.from_numpy(u + k), torch.from_numpy(st), torch.from_numpy(it + k))
+    lu, ls, li = g.finish()
+    assert torch.equal(lu, gu + 2) and torch.equal(ls, gs) and torch.equal(li, gi + 2)
     dist.barrier()
     if rank == 0:
         np.savez(os.path.join(out_dir, "gathered.npz"), u=gu.numpy(), st=gs.numpy(), it=gi.numpy())
