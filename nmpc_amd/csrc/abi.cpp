@@ -283,8 +283,9 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
 
     struct Field { void** p; size_t bytes; };
     const size_t d = sizeof(real_t);
-    // The last three fields are rebuilt in full by nmpc_batch_init (C) and by
-    // the first solve after it (hess, chol); nmpc_batch_reset skips them.
+    // The last four fields are rebuilt in full before they are read, by every
+    // Newton step (wabs), by nmpc_batch_init (C) and by the first solve after it
+    // (hess, chol); nmpc_batch_reset skips them.
     Field fields[] = {
         {(void**)&v.xref, B * N1 * 13 * d}, {(void**)&v.uref, B * N * 3 * d},
         {(void**)&v.wind, B * 3 * d},       {(void**)&v.c, B * N * 12 * d},
@@ -305,7 +306,7 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
     size_t total = 0;
     const size_t n_fields = sizeof fields / sizeof fields[0];
     for (size_t i = 0; i < n_fields; i++) {
-        if (i == n_fields - 3) b->reset_bytes = total;
+        if (i == n_fields - 4) b->reset_bytes = total;
         total += align_up(fields[i].bytes);
     }
     hipError_t e = hipMalloc(&b->arena, total);

@@ -76,20 +76,19 @@ __global__ void k_refs_from_waypoints(int B, const real_t* __restrict__ wp, int 
 // ------------------------------------------------------------------------
 // refs: [B][count][16] staging buffer; point i of the range goes to horizon
 // position first + i.  Control part of position p >= 1 belongs to stage p - 1.
+// One thread per entry: consecutive lanes read consecutive words.
 __global__ void k_store_refs(BatchView v, const real_t* __restrict__ refs,
                              int first, int count) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = v.B * count;
-    if (t >= total) return;
-    const int b = t / count, i = t % count, pos = first + i;
-    const real_t* r = refs + (size_t)t * 16;
-    real_t* x = v.xref + ((size_t)b * (v.N + 1) + xref_slot(v, pos)) * NS;
-#pragma unroll
-    for (int e = 0; e < NS; e++) x[e] = r[e];
-    if (pos >= 1) {
-        real_t* u = v.uref + ((size_t)b * v.N + stage_slot(v, pos - 1)) * NU;
-        u[0] = r[13]; u[1] = r[14]; u[2] = r[15];
-    }
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)v.B * count * 16) return;
+    const int e = (int)(t & 15);
+    const long p = t >> 4;
+    const int b = (int)(p / count), i = (int)(p % count), pos = first + i;
+    const real_t val = refs[t];
+    if (e < NS)
+        v.xref[((size_t)b * (v.N + 1) + xref_slot(v, pos)) * NS + e] = val;
+    else if (pos >= 1)
+        v.uref[((size_t)b * v.N + stage_slot(v, pos - 1)) * NU + (e - NS)] = val;
 }
 
 // ------------------------------------------------------------------------
@@ -525,7 +524,7 @@ __global__ void k_rti_reset(BatchView v) {
 static inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 void launch_store_refs(const BatchView& v, const real_t* refs, int first, int count, hipStream_t s) {
-    const long n = (long)v.B * count;
+    const long n = (long)v.B * count * 16;
     hipLaunchKernelGGL(k_store_refs, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, refs, first, count);
 }
 void launch_refs_from_waypoints(int B, const real_t* wp, int W, real_t t0, real_t dt, int first,
