@@ -1,5 +1,5 @@
 """Soak: warm control steps of whole batches on the GPU against the CPU port, bit for bit.
-usage: python tools/soak_warm.py B N steps seed [B N steps seed ...]"""
+usage: python tests/soak_warm.py B N steps seed [B N steps seed ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
