@@ -284,7 +284,10 @@ NMPC_DEV void store_tiles(const LineariseLds& L, int nvalid, real_t* jac, real_t
                 const int e = i * 64 + lane;
                 if (e < chunks) {
                     real_t* dst = e < jchunks ? jr + e * kPerVec : rr + (e - jchunks) * kPerVec;
-                    *reinterpret_cast<Vec16*>(dst) = *reinterpret_cast<const Vec16*>(tl + e * kPerVec);
+                    // Jacobians are next read a kernel later, after more data than the
+                    // caches hold: stored non-temporally
+                    __builtin_nontemporal_store(*reinterpret_cast<const Vec16*>(tl + e * kPerVec),
+                                                reinterpret_cast<Vec16*>(dst));
                 }
             }
         } else {

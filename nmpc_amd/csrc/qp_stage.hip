@@ -361,7 +361,8 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int e = lane + t * kWave;
-            f.c[t] = (e < NX * NZ) ? Cg[e] : 0.;
+            // (read once here, and too far from its next use to be kept on chip)
+            f.c[t] = (e < NX * NZ) ? __builtin_nontemporal_load(&Cg[e]) : 0.;
         }
         const int ly = lane < NZ ? lane : 0, lx = lane < NX ? lane : 0;
         const pair_a yk = *(const pair_a*)(I.y + 2 * s * NZ + 2 * ly);
@@ -462,7 +463,9 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
 #pragma unroll
             for (int t = 0; t < 3; t++) {
                 const int e = lane + t * kWave;
-                if (e < NX * NX) out[e] = in[e];
+                // (0.9 GB per batch of 4096 that the Newton solve reads once: streamed past
+                // the caches, which the stage vectors need more)
+                if (e < NX * NX) __builtin_nontemporal_store(in[e], &out[e]);
             }
         }
         // reads done before the next block row overwrites the slice
