@@ -395,12 +395,13 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
             up = L.ub[jv - NX] - uj;
         }
         const size_t e = zrow + jv;
-        v.qStep[e] = qs;
-        v.dz[e] = -d;
-        v.zUnc[e] = 0.0;
-        v.q[e] = 0.0;
-        v.zLow[e] = lo;
-        v.zUpp[e] = up;
+        // (a cold solve writes 0.3 GB of these before anything reads them)
+        __builtin_nontemporal_store(qs, &v.qStep[e]);
+        __builtin_nontemporal_store(-d, &v.dz[e]);
+        __builtin_nontemporal_store((real_t)0.0, &v.zUnc[e]);
+        __builtin_nontemporal_store((real_t)0.0, &v.q[e]);
+        __builtin_nontemporal_store(lo, &v.zLow[e]);
+        __builtin_nontemporal_store(up, &v.zUpp[e]);
     };
     if (active && c > 0) restage(c + 2, dot_own);
     if (active && c < 4) {          // the residual (c == 0) and the position columns against lambda_{k+1}
