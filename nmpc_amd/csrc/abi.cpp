@@ -122,6 +122,7 @@ struct nmpc_batch {
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> free_events;
     bool untimed = false;           // inside an entry point that must not create events
+    unsigned solve_lists = 0;       // instance lists made for the Newton solve so far
     bool chain_launches = false;    // inside a sequence of launches with nothing between them
     hipEvent_t chain_event = nullptr;
     double k_ms[NMPC_K_COUNT] = {0};
@@ -299,6 +300,7 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
         {(void**)&v.ieq, B * N1 * 15},      {(void**)&v.prev, B * N1 * 15},
         {(void**)&v.chg, B * N1},           {(void**)&v.sc, B * sizeof(Scalars)},
         {(void**)&v.tailCount, 16 * sizeof(int)}, {(void**)&v.tailList, 2 * B * sizeof(int)},
+        {(void**)&v.solveCount, 2 * kSolveListStride * sizeof(int)}, {(void**)&v.solveList, B * sizeof(int)},
         {(void**)&v.wabs, B * N1 * 16 * d},
         {(void**)&v.C, B * N * 180 * d},
         {(void**)&v.hess, B * N * 288 * d}, {(void**)&v.chol, B * N * 288 * d},
@@ -621,7 +623,9 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     } chain(b);
     TRY(timed(b, NMPC_K_QP_BEGIN, [&] { launch_qp_begin(v, dmeas, b->stream); }));
     for (int it = 1; it <= max_newton_iterations(); ++it) {
-        TRY(timed(b, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, b->stream); }));
+        if (newton_solve_listed(v))
+            TRY(timed(b, NMPC_K_OTHER, [&] { launch_list_solves(v, ++b->solve_lists, b->stream); }));
+        TRY(timed(b, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, b->solve_lists, b->stream); }));
         TRY(timed(b, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, it + 1, b->stream); }));
         if (line_search_tail_enabled(v))
             TRY(timed(b, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, b->stream); }));

@@ -63,6 +63,9 @@ struct Scalars {        // one per instance
     int lsDeferred;
 };
 
+constexpr int kSolveListBuckets = 128;
+constexpr int kSolveListStride = 2 * kSolveListBuckets + 16;
+
 struct BatchView {
     int B, N;
     int b0, nb;         // instance range [b0, b0 + nb) the QP kernels of one launch cover
@@ -96,6 +99,9 @@ struct BatchView {
     int* tailCount;     // [16] step-length searches handed on, per Newton iteration: [0..7] by
                         //      k_newton_step, [8..15] those k_line_search_fast left open
     int* tailList;      // [2][B] their instances
+    int* solveCount;    // [2][kSolveListStride] counters of the Newton solve's instance lists, two
+                        //      alternating sets: histogram by first block to factorise, fill cursors, total
+    int* solveList;     // [B] instances with a Newton system to solve, longest sweeps first
     real_t H[15];       // regular-stage Hessian diagonal as the solver sees it
     real_t Ht[12];      // terminal-stage Hessian diagonal
     real_t lb[3], ub[3];

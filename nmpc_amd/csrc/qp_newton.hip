@@ -454,15 +454,24 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 // dual_qp.c:601-698 followed by :993-1055
 // WAVES = 1: one wavefront per SIMD, block rows prefetched into registers (more
 // than 256 of them).  WAVES = 2: two per SIMD, block rows staged through LDS.
+// Large grids (WAVES = 2) take their instances from the list k_list_fill has just
+// made: only instances whose solve is still running, those with the longest
+// factorisation sweep first, so that the four groups of a wavefront have sweeps
+// of about the same length and wavefronts without work are not started at all.
+// An instance's results do not depend on which instances share its wavefront.
 template <int WAVES>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-void k_newton_solve(BatchView v) {
+void k_newton_solve(BatchView v, const int* __restrict__ list, const int* __restrict__ listed) {
+    constexpr bool LISTED = WAVES == 2;
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
-    const int bEnd = v.b0 + v.nb;
-    const int bRaw = v.b0 + blockIdx.x * kGroupsPerWave + g;
-    const int b = bRaw < bEnd ? bRaw : bEnd - 1;
+    const int count = LISTED ? *listed : v.nb;
+    const int first = blockIdx.x * kGroupsPerWave;
+    if (first >= count) return;
+    const bool have = first + g < count;
+    const int slot = have ? first + g : count - 1;
+    const int b = LISTED ? list[slot] : v.b0 + slot;
     Inst I = instance(v, b);
-    bool live = (bRaw < bEnd) && (I.sc->status == ST_RUNNING);
+    bool live = have && (I.sc->status == ST_RUNNING);
     if (!__any(live)) return;
     const int N = v.N;
     const int last = I.sc->last;
@@ -494,21 +503,100 @@ void k_newton_solve(BatchView v) {
     forward_pass(v, I, live, t);
 }
 
+// ------------------------------------------------------------------------
+// Instance list of a large grid's Newton solve: a counting sort of the running
+// instances by the block their factorisation starts from (dual_qp.c:611-623:
+// min(lastActSetChangeIdx, N - 1)), in two launches.  After the first Newton
+// iteration most instances refactorise a few blocks at the top of the horizon
+// and some the whole of it; a wavefront factorises what its longest group needs,
+// so four neighbours in instance order cost about three times the blocks that
+// four neighbours in this order do.
+constexpr int kListThreads = 256;
+
+NMPC_DEV int solve_list_bucket(const BatchView& v, const Scalars& s) {
+    if (s.status != ST_RUNNING) return -1;
+    const int start = s.last < 0 ? 0 : (s.last < v.N - 1 ? s.last : v.N - 1);
+    const int bucket = v.N <= kSolveListBuckets ? start : (int)((long)start * kSolveListBuckets / v.N);
+    return kSolveListBuckets - 1 - bucket;          // longest sweeps first
+}
+
+__global__ __launch_bounds__(kListThreads) void k_list_count(BatchView v, int* __restrict__ ctr) {
+    __shared__ int hist[kSolveListBuckets];
+    const int tid = threadIdx.x;
+    if (tid < kSolveListBuckets) hist[tid] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * kListThreads + tid;
+    if (i < v.nb) {
+        const int bucket = solve_list_bucket(v, v.sc[v.b0 + i]);
+        if (bucket >= 0) atomicAdd(&hist[bucket], 1);
+    }
+    __syncthreads();
+    if (tid < kSolveListBuckets && hist[tid] != 0) atomicAdd(&ctr[tid], hist[tid]);
+}
+
+// ctr: this launch's counters (histogram complete); spare: the other set, which
+// the next list will count into and which nothing reads any more.
+__global__ __launch_bounds__(kListThreads) void k_list_fill(BatchView v, int* __restrict__ ctr,
+                                                            int* __restrict__ spare) {
+    static_assert(kSolveListBuckets == 2 * kWave, "two buckets per lane of the first wavefront");
+    __shared__ int base[kSolveListBuckets];
+    const int tid = threadIdx.x;
+    if (tid < kWave) {
+        const int a = ctr[2 * tid], c = ctr[2 * tid + 1];
+        int sum = a + c;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int y = __shfl_up(sum, o);
+            if (tid >= o) sum += y;
+        }
+        base[2 * tid] = sum - a - c;
+        base[2 * tid + 1] = sum - c;
+        if (blockIdx.x == 0 && tid == kWave - 1) ctr[2 * kSolveListBuckets] = sum;
+    }
+    if (blockIdx.x == 0)
+        for (int j = tid; j < kSolveListStride; j += kListThreads) spare[j] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * kListThreads + tid;
+    if (i < v.nb) {
+        const int bucket = solve_list_bucket(v, v.sc[v.b0 + i]);
+        if (bucket >= 0)
+            v.solveList[base[bucket] + atomicAdd(&ctr[kSolveListBuckets + bucket], 1)] = v.b0 + i;
+    }
+}
+
 // Two wavefronts per SIMD only pay once there are wavefronts for it: the
 // dispatcher packs the workgroups of a grid onto CUs as densely as the
 // kernel's resources allow, so a grid of one wavefront per SIMD (1024 on this
 // chip) launched with the two-per-SIMD kernel leaves half of the SIMDs idle
 // (0.77 ms instead of 0.55 ms per launch at 4096 instances).
-void launch_newton_solve(const BatchView& v, hipStream_t s) {
-    const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
+bool newton_solve_listed(const BatchView& v) {
     // (the staged form's LDS image is laid out for 8-byte entries)
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds take the staged form at every size
-    const bool two = kDoublePrecision;
+    return kDoublePrecision;
 #else
-    const bool two = kDoublePrecision && blocks > kOneWavePerSimd * 3 / 2;
+    const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
+    return kDoublePrecision && blocks > kOneWavePerSimd * 3 / 2;
 #endif
-    if (two) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
-    else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);
+}
+
+// epoch: a count of the lists made for this batch; it picks the counter set.
+void launch_list_solves(const BatchView& v, unsigned epoch, hipStream_t s) {
+    int* ctr = v.solveCount + (epoch & 1) * kSolveListStride;
+    int* spare = v.solveCount + ((epoch + 1) & 1) * kSolveListStride;
+    const unsigned blocks = (unsigned)((v.nb + kListThreads - 1) / kListThreads);
+    hipLaunchKernelGGL(k_list_count, dim3(blocks), dim3(kListThreads), 0, s, v, ctr);
+    hipLaunchKernelGGL(k_list_fill, dim3(blocks), dim3(kListThreads), 0, s, v, ctr, spare);
+}
+
+void launch_newton_solve(const BatchView& v, unsigned epoch, hipStream_t s) {
+    const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
+    if (newton_solve_listed(v)) {
+        const int* ctr = v.solveCount + (epoch & 1) * kSolveListStride;
+        hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v, v.solveList,
+                           ctr + 2 * kSolveListBuckets);
+    } else {
+        hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v, nullptr, nullptr);
+    }
 }
 
 }  // namespace nmpc

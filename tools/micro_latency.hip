@@ -30,7 +30,7 @@ __global__ void k_chain(int n, T seed, T* out, long long* cycles, long long* tic
 }
 
 template <typename T, int CHAINS, int OP>
-void run(const char* name, int waves) {
+void run(const char* name, int waves, int lanes = 64) {
     T* out; long long *cyc, *tk;
     hipMalloc(&out, sizeof(T) * 64 * 64);
     hipMalloc(&cyc, 8); hipMalloc(&tk, 8);
@@ -38,7 +38,7 @@ void run(const char* name, int waves) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k_chain<T, CHAINS, OP>), dim3(1), dim3(64 * waves), 0, 0, n, (T)1.0, out, cyc, tk);
+        hipLaunchKernelGGL((k_chain<T, CHAINS, OP>), dim3(1), dim3(lanes * waves), 0, 0, n, (T)1.0, out, cyc, tk);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
     }
@@ -46,8 +46,8 @@ void run(const char* name, int waves) {
     long long c, t;
     hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(&t, tk, 8, hipMemcpyDeviceToHost);
     const double ops = (double)n * 8;
-    printf("%-10s chains %d waves/block %2d: clock64 %.2f per op-step, wall ticks(100MHz) %.3f per op-step -> %.1f ns, event %.3f ms (%.2f ns per op-step)\n",
-           name, CHAINS, waves, c / ops, t / ops, t / ops * 10.0, ms, ms * 1e6 / ops);
+    printf("%-10s lanes %2d chains %d waves/block %2d: clock64 %.2f per op-step, wall ticks(100MHz) %.3f per op-step -> %.1f ns, event %.3f ms (%.2f ns per op-step)\n",
+           name, lanes, CHAINS, waves, c / ops, t / ops, t / ops * 10.0, ms, ms * 1e6 / ops);
     hipFree(out); hipFree(cyc); hipFree(tk);
 }
 
@@ -61,5 +61,9 @@ int main() {
     run<double, 1, 0>("add_f64", 4); run<double, 1, 0>("add_f64", 8); run<double, 1, 0>("add_f64", 12);
     run<double, 1, 0>("add_f64", 16);
     run<double, 2, 0>("add_f64", 8); run<double, 2, 0>("add_f64", 12);
+    // a lone wavefront with 16 or 32 of its 64 lanes enabled: does the SIMD skip the empty quarters?
+    run<double, 1, 0>("add_f64", 1, 16); run<double, 4, 0>("add_f64", 1, 16); run<double, 8, 0>("add_f64", 1, 16);
+    run<double, 4, 0>("add_f64", 1, 32); run<double, 8, 0>("add_f64", 1, 32); run<double, 8, 0>("add_f64", 1, 64);
+    run<double, 8, 1>("mul_f64", 1, 16); run<double, 8, 1>("mul_f64", 1, 64);
     return 0;
 }
