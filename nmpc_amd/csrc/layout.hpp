@@ -63,6 +63,20 @@ struct Scalars {        // one per instance
     int lsDeferred;
 };
 
+// Block row of the factor (chol): the sub-diagonal block, rows of twelve, then
+// the lower triangle of the diagonal block, row l as l + 1 entries padded to an
+// even count.  The entries right of the diagonal, which the reference never
+// writes (dual_qp.c:832-903) and which stay zero in its [12][24] rows, are not
+// stored: 228 values instead of 288.  The rows of the triangle are placed so
+// that none crosses a multiple of 24 values (the piece one LDS-DMA instruction
+// of k_newton_solve brings in per instance).
+constexpr int kCholRow = 228;
+constexpr int kCholDiagRow[12] = {144 + 82, 144 + 70, 144 + 78, 144 + 44, 144 + 72, 144 + 64,
+                                  144 + 56, 144 + 48, 144 + 34, 144 + 24, 144 + 12, 144 + 0};
+// Reads of a row's first twelve values, whatever its length, stay inside the
+// field: its allocation ends with this many spare values.
+constexpr int kCholSlack = 16;
+
 constexpr int kSolveListBuckets = 128;
 constexpr int kSolveListStride = 2 * kSolveListBuckets + 16;
 
@@ -91,7 +105,7 @@ struct BatchView {
     real_t* dl;         // [B][N][12]
     real_t* grad;       // [B][N][12]
     real_t* hess;       // [B][N][12][24] "[L D]" block rows (types.h:265-283)
-    real_t* chol;       // [B][N][12][24]
+    real_t* chol;       // [B][N][kCholRow] (+ kCholSlack)
     int8_t* ieq;        // [B][N+1][15]
     int8_t* prev;       // [B][N+1][15]
     int8_t* chg;        // [B][N+1]       actSetHasChanged

@@ -86,7 +86,7 @@ NMPC_DEV Inst instance(const BatchView& v, int b) {
     I.dl = v.dl + sb * N * NX;
     I.grad = v.grad + sb * N * NX;
     I.hess = v.hess + sb * N * 2 * NX * NX;
-    I.chol = v.chol + sb * N * 2 * NX * NX;
+    I.chol = v.chol + sb * N * kCholRow;
     I.ieq = v.ieq + sb * N1 * NZ;
     I.prev = v.prev + sb * N1 * NZ;
     I.chg = v.chg + sb * N1;

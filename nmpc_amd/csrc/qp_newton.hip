@@ -239,6 +239,15 @@ NMPC_DEV void fetch_rows_to_lds(const real_t* g0, lds_bytes image, std::integer_
      ...);
 }
 
+// Where row l of the factor's diagonal block starts in a block row, l known only at run time.
+NMPC_DEV int chol_diag_row(int l) {
+    int at = kCholDiagRow[0];
+#pragma unroll
+    for (int i = 1; i < NX; i++) at = (l == i) ? kCholDiagRow[i] : at;
+    return at;
+}
+constexpr int kCholPieces = (kCholRow + 2 * NX - 1) / (2 * NX);     // LDS-DMA pieces of 24 values
+
 // Entry t of a 12-vector held in registers, t known only at run time.
 NMPC_DEV real_t L_diag(const real_t (&L)[NX], int t) {
     real_t d = L[0];
@@ -296,20 +305,32 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
 #pragma unroll
         for (int l = 0; l < NX; l++) { nL[l] = 0.; nLs[l] = 0.; }
     }
+    // Lanes right of the diagonal (t > l) receive whatever follows row l in a factor
+    // block row: they only ever feed their own, unused sums.
+    const int diagAt = chol_diag_row(tc) + tc;
     auto fetch_block_row = [&](bool fromH, int kk) {
-        const real_t* src = fromH ? I.hess : I.chol;
         if constexpr (STAGED) {
-            const real_t* g0 = src + (size_t)kk * (2 * NX * NX) + 2 * tc;
-            if (active && col) fetch_rows_to_lds(g0, image, Seq12{});
+            if (fromH) {
+                const real_t* g0 = I.hess + (size_t)kk * (2 * NX * NX) + 2 * tc;
+                if (active && col) fetch_rows_to_lds(g0, image, Seq12{});
+            } else {
+                const real_t* g0 = I.chol + (size_t)kk * kCholRow + 2 * tc;
+                if (active && col)
+                    fetch_rows_to_lds(g0, image, std::make_integer_sequence<int, kCholPieces>{});
+            }
             if (active) ng = I.grad[kk * NX + tc];
         } else if (active) {
+            // one load per value, its place chosen between the two layouts (a choice
+            // between two loaded values would fetch both)
+            const real_t* row = (fromH ? I.hess + (size_t)kk * (2 * NX * NX)
+                                       : I.chol + (size_t)kk * kCholRow) + tc;
 #pragma unroll
             for (int l = 0; l < NX; l++) {
-                nL[l] = HS(src, kk, 0, l, tc);
-                nLs[l] = HS(src, kk, -1, l, tc);
+                nL[l] = row[fromH ? l * 2 * NX + NX : kCholDiagRow[l]];
+                nLs[l] = row[fromH ? l * 2 * NX : NX * l];
             }
+            if (!fromH) nd = I.chol[(size_t)kk * kCholRow + diagAt];
             ng = I.grad[kk * NX + tc];
-            if (!fromH) nd = HS(I.chol, kk, 0, tc, tc);
         }
     };
     bool nextFromHess = __any(active && N - 1 <= start);
@@ -323,10 +344,14 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         if constexpr (STAGED) {
             // the block row fetched during the last iteration has landed ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // value o of a factor block row sits in piece o / 24 at o % 24; one read
+            // per value, its place chosen between the two layouts
+            const real_t* mine = rows + slot + tc;
 #pragma unroll
             for (int l = 0; l < NX; l++) {
-                Ls[l] = rows[l * 128 + slot + tc];
-                L[l] = rows[l * 128 + slot + NX + tc];
+                Ls[l] = mine[fromHess ? l * 128 : (l / 2) * 128 + (l % 2) * NX];
+                L[l] = mine[fromHess ? l * 128 + NX
+                                     : (kCholDiagRow[l] / (2 * NX)) * 128 + kCholDiagRow[l] % (2 * NX)];
             }
             // ... and is in registers before the next one overwrites the image
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -364,17 +389,17 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
                 factor_columns<false>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
             }
             if (factorThis && col) {
-                // whole rows: the entries right of the diagonal are zero in the
-                // reference's factor too (it never writes them).  A failed pivot in
-                // column failCol ends the reference's factorisation before it writes
-                // row failCol (dual_qp.c:855-866): the rows below it stay as they were.
+                // A failed pivot in column failCol ends the reference's factorisation
+                // before it writes row failCol (dual_qp.c:855-866): the rows below it
+                // stay as they were.
+                real_t* row = I.chol + (size_t)k * kCholRow;
 #pragma unroll
                 for (int l = 0; l < NX; l++)
-                    if (l > failCol) HS(I.chol, k, 0, l, t) = (l >= t) ? L[l] : 0.;
+                    if (l > failCol && l >= t) row[kCholDiagRow[l] + t] = L[l];
                 if (k > 0) {
 #pragma unroll
                     for (int l = 0; l < NX; l++)
-                        if (l > failCol) HS(I.chol, k, -1, l, t) = Ls[l];
+                        if (l > failCol) row[NX * l + t] = Ls[l];
                 }
             }
             if (factorThis && failCol >= 0) status = ST_DIV_ZERO;
@@ -411,27 +436,31 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
     real_t nLd[NX], nLr[NX], nsum = 0., nd = 1.;
 #pragma unroll
     for (int j = 0; j < NX; j++) { nLd[j] = 0.; nLr[j] = 0.; }
-    if (live) {
+    // Row tc of both blocks, twelve values each: past the diagonal the values are
+    // those of the rows stored behind it, and they only reach sums whose result
+    // has been taken already (a row is finished at its own column).
+    const int diagRow = chol_diag_row(tc);
+    auto fetch_rows = [&](int kk) {
+        const real_t* row = I.chol + (size_t)kk * kCholRow;
+        const pair_a* pd = (const pair_a*)(row + diagRow);
+        const pair_a* pr = (const pair_a*)(row + NX * tc);
 #pragma unroll
-        for (int j = 0; j < NX; j++) { nLd[j] = HS(I.chol, 0, 0, tc, j); nLr[j] = HS(I.chol, 0, -1, tc, j); }
-        nsum = I.tmp[tc];
-        nd = HS(I.chol, 0, 0, tc, tc);
-    }
+        for (int j = 0; j < NX / 2; j++) {
+            const pair_a d = pd[j], r = pr[j];
+            nLd[2 * j] = d.x; nLd[2 * j + 1] = d.y;
+            nLr[2 * j] = r.x; nLr[2 * j + 1] = r.y;
+        }
+        nsum = I.tmp[kk * NX + tc];
+        nd = row[diagRow + tc];
+    };
+    if (live) fetch_rows(0);
     for (int k = 0; k < N; ++k) {
         real_t Ld[NX], Lr[NX];
 #pragma unroll
         for (int j = 0; j < NX; j++) { Ld[j] = nLd[j]; Lr[j] = nLr[j]; }
         real_t sum = nsum;
         const real_t dd = nd;
-        if (k + 1 < N && live) {
-#pragma unroll
-            for (int j = 0; j < NX; j++) {
-                nLd[j] = HS(I.chol, k + 1, 0, tc, j);
-                nLr[j] = HS(I.chol, k + 1, -1, tc, j);
-            }
-            nsum = I.tmp[(k + 1) * NX + tc];
-            nd = HS(I.chol, k + 1, 0, tc, tc);
-        }
+        if (k + 1 < N && live) fetch_rows(k + 1);
         if (k > 0) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) sum -= Lr[j] * xo[j];
