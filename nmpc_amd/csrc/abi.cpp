@@ -123,6 +123,11 @@ struct nmpc_batch {
     std::vector<hipEvent_t> free_events;
     bool untimed = false;           // inside an entry point that must not create events
     unsigned solve_lists = 0;       // instance lists made for the Newton solve so far
+    // A Newton iteration of a mid-sized batch runs as two parts side by side: the
+    // instances with long factorisation sweeps on the batch's stream, the others
+    // on this one, between a fork and a join event.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
     bool chain_launches = false;    // inside a sequence of launches with nothing between them
     hipEvent_t chain_event = nullptr;
     double k_ms[NMPC_K_COUNT] = {0};
@@ -299,7 +304,7 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
         {(void**)&v.dl, B * N * 12 * d},    {(void**)&v.grad, B * N * 12 * d},
         {(void**)&v.ieq, B * N1 * 15},      {(void**)&v.prev, B * N1 * 15},
         {(void**)&v.chg, B * N1},           {(void**)&v.sc, B * sizeof(Scalars)},
-        {(void**)&v.tailCount, 16 * sizeof(int)}, {(void**)&v.tailList, 2 * B * sizeof(int)},
+        {(void**)&v.tailCount, 32 * sizeof(int)}, {(void**)&v.tailList, 4 * B * sizeof(int)},
         {(void**)&v.solveCount, 2 * kSolveListStride * sizeof(int)}, {(void**)&v.solveList, B * sizeof(int)},
         {(void**)&v.wabs, B * N1 * 16 * d},
         {(void**)&v.C, B * N * 180 * d},
@@ -334,6 +339,18 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
     memset(b->wt, 0, sizeof b->wt); memset(b->lb, 0, sizeof b->lb);
     memset(b->ub, 0, sizeof b->ub);
     b->fresh.assign(N, 1);
+    if (instances >= 512) {     // batches that run their Newton iterations as two parts
+        if (hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&b->fork_event, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b->join_event, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (b->fork_event) (void)hipEventDestroy(b->fork_event);
+            if (b->join_event) (void)hipEventDestroy(b->join_event);
+            if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
+            b->side_stream = nullptr;       // one part then
+            b->fork_event = b->join_event = nullptr;
+        }
+    }
     *out = b;
     return 0;
 }
@@ -352,6 +369,12 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
     if (b->plant) (void)hipFree(b->plant);
     if (b->plant_next) (void)hipFree(b->plant_next);
     if (b->arena) (void)hipFree(b->arena);
+    if (b->side_stream) {
+        (void)hipStreamSynchronize(b->side_stream);
+        (void)hipEventDestroy(b->fork_event);
+        (void)hipEventDestroy(b->join_event);
+        (void)hipStreamDestroy(b->side_stream);
+    }
     if (b->own_stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return 0;
@@ -603,6 +626,29 @@ int nmpc_batch_relinearise(nmpc_batch_t* b) {
     return 0;
 }
 
+namespace {
+
+// Newton system, step and step-length searches of iteration `it` for the instances of view v.
+int newton_iteration(nmpc_batch* b, const BatchView& v, int it, hipStream_t s) {
+    TRY(timed_on(b, s, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, s); }));
+    TRY(timed_on(b, s, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, it + 1, s); }));
+    if (line_search_tail_enabled(v))
+        TRY(timed_on(b, s, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, s); }));
+    return 0;
+}
+
+// Below the size at which the solve fills the chip twice over, its launches last as
+// long as the longest factorisation sweep, which after the first iteration a sixth of
+// the instances have, and most of the chip idles meanwhile; the instances with short
+// sweeps then go through their iteration beside it.  Small batches are bound by the
+// number of launches, which this doubles.
+bool two_parts(const nmpc_batch* b) {
+    static const bool off = getenv("NMPC_ONE_PART") != nullptr;
+    return !off && b->side_stream && b->v.nb >= 512 && !newton_solve_two_waves(b->v);
+}
+
+}  // namespace
+
 int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     if (!b || !measurement) return fail(NMPC_E_ARG, "nmpc_batch_feedback_step: null argument");
     if (!b->initialised) return fail(NMPC_E_STATE, "nmpc_batch_feedback_step before nmpc_batch_init");
@@ -621,14 +667,41 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
         explicit ChainScope(nmpc_batch* bb) : b(bb) { b->chain_launches = true; b->chain_event = nullptr; }
         ~ChainScope() { b->chain_launches = false; b->chain_event = nullptr; }
     } chain(b);
+    // After a linearisation of every stage the first Newton system is factorised in
+    // full for every instance: nothing to run beside it.
+    const bool all_fresh = std::all_of(b->fresh.begin(), b->fresh.end(), [](char f) { return f != 0; });
     TRY(timed(b, NMPC_K_QP_BEGIN, [&] { launch_qp_begin(v, dmeas, b->stream); }));
     for (int it = 1; it <= max_newton_iterations(); ++it) {
-        if (newton_solve_listed(v))
+        if (two_parts(b) && !(it == 1 && all_fresh)) {
             TRY(timed(b, NMPC_K_OTHER, [&] { launch_list_solves(v, ++b->solve_lists, b->stream); }));
-        TRY(timed(b, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, b->solve_lists, b->stream); }));
-        TRY(timed(b, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, it + 1, b->stream); }));
-        if (line_search_tail_enabled(v))
-            TRY(timed(b, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, b->stream); }));
+            HIP_TRY(hipEventRecord(b->fork_event, b->stream));
+            HIP_TRY(hipStreamWaitEvent(b->side_stream, b->fork_event, 0));
+            TRY(newton_iteration(b, solve_list_view(v, b->solve_lists, 1), it, b->stream));
+            {
+                // intervals timed on the other stream do not continue the ones of this stream
+                hipEvent_t kept = b->chain_event;
+                b->chain_launches = false;
+                const int rc = newton_iteration(b, solve_list_view(v, b->solve_lists, 2), it, b->side_stream);
+                b->chain_launches = true;
+                b->chain_event = kept;
+                TRY(rc);
+            }
+            HIP_TRY(hipEventRecord(b->join_event, b->side_stream));
+            HIP_TRY(hipStreamWaitEvent(b->stream, b->join_event, 0));
+            b->chain_event = nullptr;
+        } else if (newton_solve_two_waves(v)) {
+            // a grid that fills the chip several times over: the solve takes the running
+            // instances in the order of the list, the kernels with one workgroup per instance
+            // gain nothing from it
+            TRY(timed(b, NMPC_K_OTHER, [&] { launch_list_solves(v, ++b->solve_lists, b->stream); }));
+            const BatchView listed = solve_list_view(v, b->solve_lists, 0);
+            TRY(timed(b, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(listed, b->stream); }));
+            TRY(timed(b, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, it + 1, b->stream); }));
+            if (line_search_tail_enabled(v))
+                TRY(timed(b, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, b->stream); }));
+        } else {
+            TRY(newton_iteration(b, v, it, b->stream));
+        }
     }
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_qp_finish(v, b->stream); }));
     std::fill(b->fresh.begin(), b->fresh.end(), 0);     // every stage now carries a solution

@@ -22,12 +22,17 @@ void launch_linearise_free(long n, const real_t* x, const real_t* u, const real_
 void launch_rk4_free(long n, const real_t* x, const real_t* u, const real_t* wind, real_t delta,
                      real_t* out, hipStream_t s);
 void launch_qp_begin(const BatchView& v, const real_t* meas, hipStream_t s);
-// Large batches solve their Newton systems from a list of the running instances
-// (newton_solve_listed): launch_list_solves makes list number `epoch`, which
-// launch_newton_solve is then given; the number only has to go up by one per list.
-bool newton_solve_listed(const BatchView& v);
+// List of the instances whose solve is still running, longest factorisation
+// sweeps first: launch_list_solves makes list number `epoch` (the number only has
+// to go up by one per list), solve_list_view gives the view of the batch whose
+// Newton-iteration kernels (launch_newton_solve, launch_newton_step,
+// launch_line_search_tail) cover part 0: the whole list, 1: the long sweeps,
+// 2: the rest, with step-length search lists of its own so that parts 1 and 2 can
+// run side by side.
+bool newton_solve_two_waves(const BatchView& v);
 void launch_list_solves(const BatchView& v, unsigned epoch, hipStream_t s);
-void launch_newton_solve(const BatchView& v, unsigned epoch, hipStream_t s);
+BatchView solve_list_view(const BatchView& v, unsigned epoch, int part);
+void launch_newton_solve(const BatchView& v, hipStream_t s);
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s);
 bool line_search_tail_enabled(const BatchView& v);
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s);

@@ -79,6 +79,11 @@ constexpr int kCholSlack = 16;
 
 constexpr int kSolveListBuckets = 128;
 constexpr int kSolveListStride = 2 * kSolveListBuckets + 16;
+// (begin, end) pairs behind the histogram and the cursors: the whole list, its
+// leading part with long factorisation sweeps, the rest
+constexpr int kSolveRangeAll = 2 * kSolveListBuckets;
+constexpr int kSolveRangeLong = kSolveRangeAll + 2;
+constexpr int kSolveRangeShort = kSolveRangeAll + 4;
 
 struct BatchView {
     int B, N;
@@ -113,9 +118,16 @@ struct BatchView {
     int* tailCount;     // [16] step-length searches handed on, per Newton iteration: [0..7] by
                         //      k_newton_step, [8..15] those k_line_search_fast left open
     int* tailList;      // [2][B] their instances
+                        //      (both allocated twice: the second set serves the view of the
+                        //      instances with short sweeps when an iteration runs as two parts)
     int* solveCount;    // [2][kSolveListStride] counters of the Newton solve's instance lists, two
-                        //      alternating sets: histogram by first block to factorise, fill cursors, total
+                        //      alternating sets: histogram by first block to factorise, fill
+                        //      cursors, then the ranges kSolveRange* of the list
     int* solveList;     // [B] instances with a Newton system to solve, longest sweeps first
+    // Instances the Newton-iteration kernels of one launch cover: entries
+    // [listRange[0], listRange[1]) of list, or all of [b0, b0 + nb) when list is null.
+    const int* list;
+    const int* listRange;
     real_t H[15];       // regular-stage Hessian diagonal as the solver sees it
     real_t Ht[12];      // terminal-stage Hessian diagonal
     real_t lb[3], ub[3];

@@ -94,6 +94,15 @@ NMPC_DEV Inst instance(const BatchView& v, int b) {
     return I;
 }
 
+// Instance that item i (a workgroup, or a 16-lane group) of a launch works on, -1: none.
+NMPC_DEV int launch_instance(const BatchView& v, int i) {
+    if (v.list) {
+        const int at = v.listRange[0] + i;
+        return at < v.listRange[1] ? v.list[at] : -1;
+    }
+    return i < v.nb ? v.b0 + i : -1;
+}
+
 NMPC_DEV const real_t* stage_hessian(const BatchView& v, int k) {
     return k < v.N ? v.H : v.Ht;
 }

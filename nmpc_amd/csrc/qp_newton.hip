@@ -483,22 +483,24 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 // dual_qp.c:601-698 followed by :993-1055
 // WAVES = 1: one wavefront per SIMD, block rows prefetched into registers (more
 // than 256 of them).  WAVES = 2: two per SIMD, block rows staged through LDS.
-// Large grids (WAVES = 2) take their instances from the list k_list_fill has just
-// made: only instances whose solve is still running, those with the longest
-// factorisation sweep first, so that the four groups of a wavefront have sweeps
-// of about the same length and wavefronts without work are not started at all.
-// An instance's results do not depend on which instances share its wavefront.
+// With a list in the view (k_list_fill has just made it) the groups take only
+// instances whose solve is still running, those with the longest factorisation
+// sweep first, so that the four groups of a wavefront have sweeps of about the
+// same length and wavefronts without work end at once.  An instance's results
+// do not depend on which instances share its wavefront.
 template <int WAVES>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-void k_newton_solve(BatchView v, const int* __restrict__ list, const int* __restrict__ listed) {
-    constexpr bool LISTED = WAVES == 2;
+void k_newton_solve(BatchView v) {
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
-    const int count = LISTED ? *listed : v.nb;
     const int first = blockIdx.x * kGroupsPerWave;
-    if (first >= count) return;
-    const bool have = first + g < count;
-    const int slot = have ? first + g : count - 1;
-    const int b = LISTED ? list[slot] : v.b0 + slot;
+    const int b0 = launch_instance(v, first);
+    if (b0 < 0) return;
+    // One dependent chain per wavefront: when wavefronts of other kernels share the
+    // SIMD (the other part of a two-part iteration), this one issues first.
+    if (WAVES == 1) __builtin_amdgcn_s_setprio(3);
+    const int bg = launch_instance(v, first + g);
+    const bool have = bg >= 0;
+    const int b = have ? bg : b0;
     Inst I = instance(v, b);
     bool live = have && (I.sc->status == ST_RUNNING);
     if (!__any(live)) return;
@@ -565,11 +567,14 @@ __global__ __launch_bounds__(kListThreads) void k_list_count(BatchView v, int* _
 
 // ctr: this launch's counters (histogram complete); spare: the other set, which
 // the next list will count into and which nothing reads any more.
+// longBuckets: the leading buckets whose instances count as long sweeps.
 __global__ __launch_bounds__(kListThreads) void k_list_fill(BatchView v, int* __restrict__ ctr,
-                                                            int* __restrict__ spare) {
+                                                            int* __restrict__ spare, int longBuckets) {
     static_assert(kSolveListBuckets == 2 * kWave, "two buckets per lane of the first wavefront");
-    __shared__ int base[kSolveListBuckets];
+    __shared__ int base[kSolveListBuckets + 1];
+    __shared__ int mine[kSolveListBuckets];         // this workgroup's instances per bucket
     const int tid = threadIdx.x;
+    if (tid < kSolveListBuckets) mine[tid] = 0;
     if (tid < kWave) {
         const int a = ctr[2 * tid], c = ctr[2 * tid + 1];
         int sum = a + c;
@@ -580,17 +585,26 @@ __global__ __launch_bounds__(kListThreads) void k_list_fill(BatchView v, int* __
         }
         base[2 * tid] = sum - a - c;
         base[2 * tid + 1] = sum - c;
-        if (blockIdx.x == 0 && tid == kWave - 1) ctr[2 * kSolveListBuckets] = sum;
+        if (tid == kWave - 1) base[kSolveListBuckets] = sum;
     }
     if (blockIdx.x == 0)
         for (int j = tid; j < kSolveListStride; j += kListThreads) spare[j] = 0;
     __syncthreads();
-    const int i = blockIdx.x * kListThreads + tid;
-    if (i < v.nb) {
-        const int bucket = solve_list_bucket(v, v.sc[v.b0 + i]);
-        if (bucket >= 0)
-            v.solveList[base[bucket] + atomicAdd(&ctr[kSolveListBuckets + bucket], 1)] = v.b0 + i;
+    if (blockIdx.x == 0 && tid == 0) {
+        const int total = base[kSolveListBuckets], nLong = base[longBuckets];
+        ctr[kSolveRangeAll] = 0;       ctr[kSolveRangeAll + 1] = total;
+        ctr[kSolveRangeLong] = 0;      ctr[kSolveRangeLong + 1] = nLong;
+        ctr[kSolveRangeShort] = nLong; ctr[kSolveRangeShort + 1] = total;
     }
+    // one cursor update per workgroup and bucket (a cold solve has every instance in one bucket)
+    const int i = blockIdx.x * kListThreads + tid;
+    const int bucket = i < v.nb ? solve_list_bucket(v, v.sc[v.b0 + i]) : -1;
+    const int rank = bucket >= 0 ? atomicAdd(&mine[bucket], 1) : 0;
+    __syncthreads();
+    if (tid < kSolveListBuckets && mine[tid] != 0)
+        base[tid] += atomicAdd(&ctr[kSolveListBuckets + tid], mine[tid]);
+    __syncthreads();
+    if (bucket >= 0) v.solveList[base[bucket] + rank] = v.b0 + i;
 }
 
 // Two wavefronts per SIMD only pay once there are wavefronts for it: the
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(kListThreads) void k_list_fill(BatchView v, int* __
 // kernel's resources allow, so a grid of one wavefront per SIMD (1024 on this
 // chip) launched with the two-per-SIMD kernel leaves half of the SIMDs idle
 // (0.77 ms instead of 0.55 ms per launch at 4096 instances).
-bool newton_solve_listed(const BatchView& v) {
+bool newton_solve_two_waves(const BatchView& v) {
     // (the staged form's LDS image is laid out for 8-byte entries)
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds take the staged form at every size
     return kDoublePrecision;
@@ -613,19 +627,29 @@ void launch_list_solves(const BatchView& v, unsigned epoch, hipStream_t s) {
     int* ctr = v.solveCount + (epoch & 1) * kSolveListStride;
     int* spare = v.solveCount + ((epoch + 1) & 1) * kSolveListStride;
     const unsigned blocks = (unsigned)((v.nb + kListThreads - 1) / kListThreads);
+    // long sweeps: those that start in the lower three quarters of the horizon's blocks
+    const int nBuckets = v.N < kSolveListBuckets ? v.N : kSolveListBuckets;
+    const int longBuckets = kSolveListBuckets - nBuckets + (3 * nBuckets + 3) / 4;
     hipLaunchKernelGGL(k_list_count, dim3(blocks), dim3(kListThreads), 0, s, v, ctr);
-    hipLaunchKernelGGL(k_list_fill, dim3(blocks), dim3(kListThreads), 0, s, v, ctr, spare);
+    hipLaunchKernelGGL(k_list_fill, dim3(blocks), dim3(kListThreads), 0, s, v, ctr, spare, longBuckets);
 }
 
-void launch_newton_solve(const BatchView& v, unsigned epoch, hipStream_t s) {
-    const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
-    if (newton_solve_listed(v)) {
-        const int* ctr = v.solveCount + (epoch & 1) * kSolveListStride;
-        hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v, v.solveList,
-                           ctr + 2 * kSolveListBuckets);
-    } else {
-        hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v, nullptr, nullptr);
+BatchView solve_list_view(const BatchView& v, unsigned epoch, int part) {
+    BatchView w = v;
+    const int* ctr = v.solveCount + (epoch & 1) * kSolveListStride;
+    w.list = v.solveList;
+    w.listRange = ctr + (part == 1 ? kSolveRangeLong : part == 2 ? kSolveRangeShort : kSolveRangeAll);
+    if (part == 2 && v.tailCount) {
+        w.tailCount = v.tailCount + 16;
+        w.tailList = v.tailList + 2 * (size_t)v.B;
     }
+    return w;
+}
+
+void launch_newton_solve(const BatchView& v, hipStream_t s) {
+    const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
+    if (newton_solve_two_waves(v)) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
+    else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);
 }
 
 }  // namespace nmpc

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
     const StageLds L = carve(lds_raw, v.N);
     const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
     Inst I = instance(v, b);
-    if (blockIdx.x == 0 && tid < 16 && v.tailCount) v.tailCount[tid] = 0;
+    if (blockIdx.x == 0 && tid < 32 && v.tailCount) v.tailCount[tid] = 0;     // both sets
 
     // initial-value embedding: pin the stage-0 state to the measured deviation
     if (tid == 0) {
@@ -845,7 +845,8 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
 __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int nextIt) {
     extern __shared__ real_t lds_raw[];
     const StageLds L = carve_step(lds_raw, v.N);
-    const int b = v.b0 + blockIdx.x, tid = threadIdx.x;
+    const int b = launch_instance(v, blockIdx.x), tid = threadIdx.x;
+    if (b < 0) return;
     Inst I = instance(v, b);
     if (I.sc->status != ST_RUNNING) return;
     const int N = v.N, n = NX * N;
@@ -1512,7 +1513,11 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     }
     // what the first attempt left open
     if (v.N <= kTailMaxHorizon) {
-        const int grid = v.nb < 256 ? v.nb : 256;
+        // Each workgroup takes most of a CU's LDS, so placing one waits for the CU to
+        // drain, kernels of other streams included; after the first attempt few
+        // searches are left (about one in 5 000), and a small grid loops over them.
+        const int cap = kFirstAttempt ? 32 : 256;
+        const int grid = v.nb < cap ? v.nb : cap;
         const size_t lds = tail_lds_bytes(v.N);
         if (lds > 64 * 1024)    // beyond the default cap on dynamic LDS
             (void)hipFuncSetAttribute((const void*)k_line_search_tail,
