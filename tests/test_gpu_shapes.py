@@ -123,11 +123,15 @@ def batch_against_port(B, N, steps, seed, dumped, mutate=None):
     return sum(int((g[1] == 0).sum()) for g in got)
 
 
-@pytest.mark.parametrize("B,N,steps,seed", [(1024, 100, 5, 4242), (96, 500, 3, 4343)])
+@pytest.mark.parametrize("B,N,steps,seed", [(1024, 100, 5, 4242), (96, 500, 3, 4343),
+                                            (777, 30, 4, 4444), (6401, 20, 3, 4545)])
 def test_warm_control_steps_of_a_batch(port_built, B, N, steps, seed):
     """Warm steps are where half of the instances go through the handed-over
     step-length searches (the regrouped first attempt and the row-ordered
-    continuation; at N = 500 their long-horizon forms)."""
+    continuation; at N = 500 their long-horizon forms).  From 512 instances on a
+    Newton iteration runs as two parts on two streams, from 6 145 on the Newton
+    solve takes its instances from the sorted list: both with instance counts
+    that are no multiple of a wavefront's four."""
     converged = batch_against_port(B, N, steps, seed, dumped=24)
     assert converged > B * steps // 4        # the comparison is not vacuous
 
