@@ -70,12 +70,14 @@ METRIC = "NMPC solves/sec (prep+feedback) at batch B, default horizon"
 #                 reads x_k, u_k (128 B), writes C (1440 B) and c (96 B)
 #   newton_solve  per stage block and Newton iteration: two substitutions
 #                 (0.84 kflop) that read the factor block row once each, on the
-#                 way down and on the way up (2 x 2304 B; 230 kB of factor per
+#                 way down and on the way up (2 x 1824 B: 228 values, the
+#                 sub-diagonal block and the lower triangle; 180 kB of factor per
 #                 instance do not stay on chip between the sweeps), the
-#                 gradient (96 B) and read/write the step (3 x 96 B): 4992 B;
+#                 gradient (96 B) and read/write the step (3 x 96 B): 4032 B;
 #                 blocks that are refactorised add the reverse Cholesky of a
-#                 12x12 diagonal + 12x12 sub-diagonal block (4.2 kflop) and the
-#                 store of the factor (2304 B).  Every block is refactorised in
+#                 12x12 diagonal + 12x12 sub-diagonal block (4.2 kflop), read the
+#                 Newton Hessian's block row (2304 B) instead of the factor's on
+#                 the way down and store the factor (1824 B): 2304 B more.  Every block is refactorised in
 #                 the first iteration; later iterations refactorise from the
 #                 last active-set change down, which is not counted here.
 #   newton_setup  per stage and iteration: gradient (0.38 kflop) + Hessian
@@ -85,7 +87,7 @@ METRIC = "NMPC solves/sec (prep+feedback) at batch B, default horizon"
 #                 objective; reads C, c and the 15-vectors, writes them back
 ALGO = {
     "linearise": dict(flop=17000.0, bytes=1664.0),
-    "newton_solve": dict(flop=840.0, bytes=4992.0),
+    "newton_solve": dict(flop=840.0, bytes=4032.0),
     "newton_factor": dict(flop=4200.0, bytes=2304.0),
     "newton_setup": dict(flop=5080.0, bytes=4296.0),
     "newton_step": dict(flop=670.0, bytes=3100.0),

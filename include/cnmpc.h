@@ -117,7 +117,10 @@ enum nmpc_precision_t nmpc_config_get_precision(void);
  * 2. Batch interface.  Every function returns 0 on success or a negative
  *    NMPC_E_* code; nmpc_last_error() describes the last failure of the
  *    calling thread.  All work is queued on the batch's HIP stream and
- *    functions that return data to the host wait for it.
+ *    functions that return data to the host wait for it.  (A batch of 512
+ *    instances or more runs part of nmpc_batch_feedback_step on a second
+ *    stream of its own, forked from and joined back into the batch's stream:
+ *    work ordered behind the batch's stream is ordered behind all of it.)
  * ------------------------------------------------------------------ */
 enum {
     NMPC_E_ARG = -1,      /* bad argument (null pointer, index out of range) */
