@@ -100,7 +100,7 @@ BOUND = {"linearise": "vector-alu", "newton_solve": "hbm", "qp_begin": "hbm", "n
 LIMITER = {
     "linearise": "vector instruction issue (FMA contraction is off: the ceiling is the FMA-free rate)",
     "newton_solve": "instruction issue of one wavefront per SIMD running one dependent chain per "
-                    "instance (from 512 to 6144 instances an iteration's solve is two overlapping "
+                    "instance (from 512 instances on an iteration's solve is two overlapping "
                     "launches, long and short factorisation sweeps, each counted in full); HBM in the "
                     "launch that factorises every block and for batches that fill the chip twice over",
     "qp_begin": "HBM", "newton_step": "HBM",

@@ -637,14 +637,15 @@ int newton_iteration(nmpc_batch* b, const BatchView& v, int it, hipStream_t s) {
     return 0;
 }
 
-// Below the size at which the solve fills the chip twice over, its launches last as
-// long as the longest factorisation sweep, which after the first iteration a sixth of
-// the instances have, and most of the chip idles meanwhile; the instances with short
-// sweeps then go through their iteration beside it.  Small batches are bound by the
-// number of launches, which this doubles.
+// A launch of the solve lasts as long as the longest factorisation sweep, which after
+// the first iteration a sixth of the instances have, and below the size at which the
+// solve fills the chip twice over most of the chip idles meanwhile; the instances with
+// short sweeps then go through their iteration beside it.  Larger batches gain less
+// (2 % at 8 192 to 32 768 instances: the short part's bandwidth-bound step beside the
+// long part's solve).  Small batches are bound by the number of launches, which this doubles.
 bool two_parts(const nmpc_batch* b) {
     static const bool off = getenv("NMPC_ONE_PART") != nullptr;
-    return !off && b->side_stream && b->v.nb >= 512 && !newton_solve_two_waves(b->v);
+    return !off && b->side_stream && b->v.nb >= 512;
 }
 
 }  // namespace
