@@ -75,3 +75,29 @@ def test_state_plus_delta_inverts_state_to_delta(port_built):
     out = np.zeros(13)
     lib.port_state_plus_delta(out.ctypes.data_as(dp), x[0].ctypes.data_as(dp), z.ctypes.data_as(dp))
     assert np.array_equal(out, x[0])
+
+
+def test_factor_block_row_layout_is_a_packing():
+    """The factor's block row (nmpc_amd/csrc/layout.hpp): the 12x12 sub-diagonal
+    block, then the lower triangle of the diagonal block.  Rows of the triangle
+    start at even offsets (16-byte pieces), do not overlap each other or the
+    sub-diagonal block, stay inside the row, and none crosses a multiple of 24
+    values (one LDS-DMA piece of the Newton solve)."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "nmpc_amd", "csrc", "layout.hpp")).read()
+    row = int(re.search(r"kCholRow\s*=\s*(\d+)", src).group(1))
+    body = re.search(r"kCholDiagRow\[12\]\s*=\s*\{([^}]*)\}", src).group(1)
+    starts = [eval(e) for e in body.split(",")]         # entries are sums of two literals
+    slack = int(re.search(r"kCholSlack\s*=\s*(\d+)", src).group(1))
+    assert len(starts) == 12
+    used = np.zeros(row, dtype=int)
+    used[:144] += 1                                     # rows of twelve: the sub-diagonal block
+    for l, at in enumerate(starts):
+        assert at % 2 == 0
+        assert at // 24 == (at + l) // 24               # entries 0..l in one piece
+        used[at:at + l + 1] += 1
+        # a lane reads the first twelve values of any row: inside the row plus the slack
+        assert at + 12 <= row + slack
+    assert used.max() == 1
+    assert used.sum() == 144 + 78
