@@ -488,9 +488,18 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 // sweep first, so that the four groups of a wavefront have sweeps of about the
 // same length and wavefronts without work end at once.  An instance's results
 // do not depend on which instances share its wavefront.
+#ifdef NMPC_SOLVE_STATS
+// Measurement build (tools/solve_stats.py): cycles of the two sweeps summed over
+// wavefronts; [0..7] launches over a whole batch or the long part, [8..15] short parts.
+__device__ unsigned long long g_solve_stats[16];
+#endif
+
 template <int WAVES>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void k_newton_solve(BatchView v) {
+#ifdef NMPC_SOLVE_STATS
+    const long long c0 = clock64();
+#endif
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
     const int first = blockIdx.x * kGroupsPerWave;
     const int b0 = launch_instance(v, first);
@@ -531,7 +540,22 @@ void k_newton_solve(BatchView v) {
         }
     }
     if (!__any(live)) return;
+#ifdef NMPC_SOLVE_STATS
+    const long long c1 = clock64();
+#endif
     forward_pass(v, I, live, t);
+#ifdef NMPC_SOLVE_STATS
+    const long long c2 = clock64();
+    if (threadIdx.x == 0) {
+        const int part = (v.list && v.listRange[0] > 0) ? 8 : 0;
+        atomicAdd(&g_solve_stats[part + 0], 1ull);
+        atomicAdd(&g_solve_stats[part + 1], (unsigned long long)(c1 - c0));
+        atomicAdd(&g_solve_stats[part + 2], (unsigned long long)(c2 - c1));
+        atomicAdd(&g_solve_stats[part + 3], (unsigned long long)(wave_max(start) + 1));
+        atomicMax(&g_solve_stats[part + 4], (unsigned long long)(c1 - c0));
+        atomicMax(&g_solve_stats[part + 5], (unsigned long long)(c2 - c1));
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------
@@ -651,5 +675,17 @@ void launch_newton_solve(const BatchView& v, hipStream_t s) {
     if (newton_solve_two_waves(v)) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
     else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);
 }
+
+#ifdef NMPC_SOLVE_STATS
+extern "C" int nmpc_debug_solve_stats(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solve_stats), sizeof(unsigned long long) * 16) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long zero[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_solve_stats), zero, sizeof zero) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace nmpc
