@@ -425,55 +425,62 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
 // owns row t of each block.
 // Also leaves the squared norm of the step, summed in row order, in the
 // instance's scalars (the line search normalises with it, dual_qp.c:1305,1352).
+struct ForwardRow {     // row tc of a block row: diagonal block, sub-diagonal block, right-hand side, pivot
+    real_t Ld[NX], Lr[NX], sum, d;
+};
+
 NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) {
     const int N = v.N;
     const bool col = t < NX;
     const int tc = col ? t : 0;
-    real_t xk[NX], xo[NX];
-#pragma unroll
-    for (int j = 0; j < NX; j++) { xk[j] = 0.; xo[j] = 0.; }
     real_t norm2 = 0.;
-    real_t nLd[NX], nLr[NX], nsum = 0., nd = 1.;
-#pragma unroll
-    for (int j = 0; j < NX; j++) { nLd[j] = 0.; nLr[j] = 0.; }
     // Row tc of both blocks, twelve values each: past the diagonal the values are
     // those of the rows stored behind it, and they only reach sums whose result
     // has been taken already (a row is finished at its own column).
     const int diagRow = chol_diag_row(tc);
-    auto fetch_rows = [&](int kk) {
+    auto fetch_row = [&](int kk, ForwardRow& r) {
         const real_t* row = I.chol + (size_t)kk * kCholRow;
         const pair_a* pd = (const pair_a*)(row + diagRow);
         const pair_a* pr = (const pair_a*)(row + NX * tc);
 #pragma unroll
         for (int j = 0; j < NX / 2; j++) {
-            const pair_a d = pd[j], r = pr[j];
-            nLd[2 * j] = d.x; nLd[2 * j + 1] = d.y;
-            nLr[2 * j] = r.x; nLr[2 * j + 1] = r.y;
+            const pair_a d = pd[j], s = pr[j];
+            r.Ld[2 * j] = d.x; r.Ld[2 * j + 1] = d.y;
+            r.Lr[2 * j] = s.x; r.Lr[2 * j + 1] = s.y;
         }
-        nsum = I.tmp[kk * NX + tc];
-        nd = row[diagRow + tc];
+        r.sum = I.tmp[kk * NX + tc];
+        r.d = row[diagRow + tc];
     };
-    if (live) fetch_rows(0);
-    for (int k = 0; k < N; ++k) {
-        real_t Ld[NX], Lr[NX];
-#pragma unroll
-        for (int j = 0; j < NX; j++) { Ld[j] = nLd[j]; Lr[j] = nLr[j]; }
-        real_t sum = nsum;
-        const real_t dd = nd;
-        if (k + 1 < N && live) fetch_rows(k + 1);
+    // Block k from `cur` while block k + 1 is on its way into `nxt`; x of the block
+    // above in xin, x of this block into xout.  Two copies of the body take turns on
+    // the two sets, so nothing is moved from one to the other.
+    auto block = [&](int k, ForwardRow& cur, ForwardRow& nxt, const real_t (&xin)[NX], real_t (&xout)[NX]) {
+        if (k + 1 < N && live) fetch_row(k + 1, nxt);
+        real_t sum = cur.sum;
         if (k > 0) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) sum -= Lr[j] * xo[j];
+            for (int j = 0; j < NX; ++j) sum -= cur.Lr[j] * xin[j];
         }
         real_t mine = 0.;
-        const Pivot pv{dd, 1.0 / dd};
-        if (__any(plain_division_needed(dd)))
-            forward_columns<false>(xk, mine, sum, Ld, pv, t, Seq12{});
+        const Pivot pv{cur.d, 1.0 / cur.d};
+        if (__any(plain_division_needed(cur.d)))
+            forward_columns<false>(xout, mine, sum, cur.Ld, pv, t, Seq12{});
         else
-            forward_columns<true>(xk, mine, sum, Ld, pv, t, Seq12{});
+            forward_columns<true>(xout, mine, sum, cur.Ld, pv, t, Seq12{});
         if (live && col) I.dl[k * NX + t] = mine;
 #pragma unroll
-        for (int j = 0; j < NX; j++) { xo[j] = xk[j]; norm2 += xk[j] * xk[j]; }
+        for (int j = 0; j < NX; j++) norm2 += xout[j] * xout[j];
+    };
+    ForwardRow a, b;
+    real_t xa[NX], xb[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) { a.Ld[j] = 0.; a.Lr[j] = 0.; b.Ld[j] = 0.; b.Lr[j] = 0.; xa[j] = 0.; xb[j] = 0.; }
+    a.sum = b.sum = 0.;
+    a.d = b.d = 1.;
+    if (live) fetch_row(0, a);
+    for (int k = 0; k < N; k += 2) {
+        block(k, a, b, xb, xa);
+        if (k + 1 < N) block(k + 1, b, a, xa, xb);
     }
     if (live && t == 0) I.sc->dlNorm2 = norm2;
 }
