@@ -29,6 +29,45 @@ __global__ void k_chain(int n, T seed, T* out, long long* cycles, long long* tic
     if (threadIdx.x == 0 && blockIdx.x == 0) { *cycles = t1 - t0; *ticks = w1 - w0; }
 }
 
+// One column of the top-down substitution: quotient from a reciprocal (mul, fma, fma), row
+// broadcast, mul, sub; STEP selects how much of it runs.
+template <int STEP>
+__global__ void k_column(int n, double seed, double* out, long long* cycles, long long* ticks) {
+    double sum = seed + threadIdx.x, y = 0.5000001, d = 2.0, l = 1.0000001;
+    const long long t0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            double x = sum;
+            if (STEP >= 1) {
+                const double q0 = sum * y;
+                const double rn = __builtin_fma(d, q0, -sum);
+                x = __builtin_fma(-rn, y, q0);
+            }
+            if (STEP >= 2) x = __builtin_amdgcn_update_dpp(0.0, x, 0x150 + 3, 0xf, 0xf, true);
+            sum -= l * x;
+        }
+    }
+    const long long t1 = clock64(), w1 = wall_clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { *cycles = t1 - t0; *ticks = w1 - w0; }
+}
+
+template <int STEP>
+void run_column(const char* name) {
+    double* out; long long *cyc, *tk;
+    hipMalloc(&out, 8 * 64); hipMalloc(&cyc, 8); hipMalloc(&tk, 8);
+    const int n = 20000;
+    for (int rep = 0; rep < 2; rep++) {
+        hipLaunchKernelGGL((k_column<STEP>), dim3(1), dim3(64), 0, 0, n, 1.0, out, cyc, tk);
+        hipDeviceSynchronize();
+    }
+    long long c;
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%-40s clock64 %.2f per column\n", name, c / ((double)n * 8));
+    hipFree(out); hipFree(cyc); hipFree(tk);
+}
+
 template <typename T, int CHAINS, int OP>
 void run(const char* name, int waves, int lanes = 64) {
     T* out; long long *cyc, *tk;
@@ -65,5 +104,8 @@ int main() {
     run<double, 1, 0>("add_f64", 1, 16); run<double, 4, 0>("add_f64", 1, 16); run<double, 8, 0>("add_f64", 1, 16);
     run<double, 4, 0>("add_f64", 1, 32); run<double, 8, 0>("add_f64", 1, 32); run<double, 8, 0>("add_f64", 1, 64);
     run<double, 8, 1>("mul_f64", 1, 16); run<double, 8, 1>("mul_f64", 1, 64);
+    run_column<0>("column: mul, sub");
+    run_column<1>("column: quotient (mul, fma, fma), mul, sub");
+    run_column<2>("column: quotient, row broadcast, mul, sub");
     return 0;
 }
