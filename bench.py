@@ -177,6 +177,26 @@ def load_traffic(tag, kernel):
     return None
 
 
+def whole_step_traffic(tag, ms_per_step, peaks):
+    """HBM bytes of one whole step from the committed PMC summary (bytes per launch
+    x launches per step of every kernel in it) over the measured step time: what
+    the path as a whole takes from the memory system, next to the one kernel the
+    roofline entry prices."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % tag)
+    if REAL["name"] != "f64" or not os.path.exists(path):
+        return None
+    j = json.load(open(path))
+    per, n = j.get("bytes_per_launch", {}), j.get("launches", {})
+    steps = j.get("steps") or max(1, min(n.get("qp_begin", 1), n.get("linearise", 1)))
+    total = sum(per[k] * n.get(k, 0) for k in per) / steps
+    gbps = total / 1e9 / (ms_per_step / 1e3)
+    out = dict(traffic=round(total), GBps=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBS, 5),
+               source="profiles/r02_traffic_%s.json" % tag)
+    if peaks and peaks.get("hbm_triad_GBps"):
+        out["frac_of_measured_hbm"] = round(gbps / peaks["hbm_triad_GBps"], 5)
+    return out
+
+
 def make_roofline(kernel, kern, algo_bytes, peaks, traffic):
     k = kern[kernel]
     achieved = k["algo_GBps"]
@@ -388,6 +408,9 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     kern[dominant] = timed_kern[dominant]
     tag = "cfg%d" % a.config if (B, N) in ((4096, 100), (1024, 500)) else "b%d_n%d" % (B, N)
     roofline = make_roofline(dominant, kern, algo_bytes, peaks, load_traffic(tag, dominant))
+    whole = whole_step_traffic(tag, elapsed / a.steps * 1e3, peaks)
+    if whole:
+        roofline["whole_step"] = whole
     # the stage linearisation beside it, whichever kernel dominates
     if "linearise" in kern and dominant != "linearise":
         lin_bytes = {"linearise": ALGO["linearise"]["bytes"] * REAL["bytes"] / 8.0 * B * N

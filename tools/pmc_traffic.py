@@ -20,7 +20,9 @@ from collections import defaultdict
 SHORT = {"k_linearise": "linearise", "k_linearise_free": "linearise_free", "k_qp_begin": "qp_begin",
          "k_newton_solve": "newton_solve", "k_newton_step": "newton_step",
          "k_init_stages": "init_stages", "k_line_search_tail": "line_search_tail", "k_line_search_fast": "line_search_fast", "k_line_search_exact": "line_search_exact",
-         "k_line_search_commit": "line_search_commit", "k_line_search_hessian": "line_search_hessian"}
+         "k_line_search_commit": "line_search_commit", "k_line_search_hessian": "line_search_hessian",
+         "k_list_count": "list_count", "k_list_fill": "list_fill", "k_store_refs": "store_refs",
+         "k_qp_finish": "qp_finish", "k_gather_results": "gather_results"}
 
 
 def collect(path, counter):

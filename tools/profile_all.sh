@@ -35,6 +35,8 @@ pmc cfg2_fetch FETCH_SIZE python3 $R/tools/prof_run.py &&
 pmc cfg2_write WRITE_SIZE python3 $R/tools/prof_run.py &&
 PROF_B=1024 PROF_N=500 pmc cfg4_fetch FETCH_SIZE python3 $R/tools/prof_run.py &&
 PROF_B=1024 PROF_N=500 pmc cfg4_write WRITE_SIZE python3 $R/tools/prof_run.py &&
+PROF_B=32768 PROF_STEPS=1 pmc b32768_fetch FETCH_SIZE python3 $R/tools/prof_run.py &&
+PROF_B=32768 PROF_STEPS=1 pmc b32768_write WRITE_SIZE python3 $R/tools/prof_run.py &&
 pmc cfg5_fetch FETCH_SIZE python3 $R/tools/prof_samples.py &&
 pmc cfg5_write WRITE_SIZE python3 $R/tools/prof_samples.py &&
 pmc cfg5_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVE_CYCLES SQ_WAVES" python3 $R/tools/prof_samples.py &&
@@ -44,6 +46,7 @@ pmc cfg2_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_M
 cd $R
 python3 tools/pmc_traffic.py $out/pmc_cfg2_fetch.csv $out/pmc_cfg2_write.csv cfg2 "4096 instances, horizon 100, cold solve" &&
 python3 tools/pmc_traffic.py $out/pmc_cfg4_fetch.csv $out/pmc_cfg4_write.csv cfg4 "1024 instances, horizon 500, cold solve" &&
+python3 tools/pmc_traffic.py $out/pmc_b32768_fetch.csv $out/pmc_b32768_write.csv b32768_n100 "32768 instances, horizon 100, cold solve" &&
 python3 tools/pmc_traffic.py $out/pmc_cfg5_fetch.csv $out/pmc_cfg5_write.csv cfg5 "2^20 samples, stage linearisation" || exit 1
 python3 - $out $tag <<'PY'
 import csv, json, re, sys
