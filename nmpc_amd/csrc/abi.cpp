@@ -340,7 +340,12 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
     memset(b->ub, 0, sizeof b->ub);
     b->fresh.assign(N, 1);
     if (instances >= 512) {     // batches that run their Newton iterations as two parts
-        if (hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        // The part on the batch's stream is the one an iteration waits for: the second
+        // stream gets the lowest priority, so that the long part's step is not queued
+        // behind the thousands of workgroups of the short part's.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        if (hipStreamCreateWithPriority(&b->side_stream, hipStreamNonBlocking, least) != hipSuccess ||
             hipEventCreateWithFlags(&b->fork_event, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&b->join_event, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
