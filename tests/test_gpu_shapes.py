@@ -152,3 +152,23 @@ def test_hostile_inputs_through_the_solver(port_built):
             arr[m] = special[rng.integers(0, len(special), int(m.sum()))]
     converged = batch_against_port(160, 100, 3, 4444, dumped=160, mutate=mutate)
     assert 160 * 3 * 3 // 4 > converged > 160 * 3 // 4      # some instances fail on their inputs, the others solve
+
+
+def test_one_part_iterations_in_a_fresh_process(port_built):
+    """NMPC_ONE_PART keeps every Newton iteration on the batch's one stream (the
+    sequence batches below 512 instances always take; above 6 144 instances with
+    the listed Newton solve): same results, checked by the soak tool in a child
+    process because the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMPC_ONE_PART="1", SOAK_DUMPS="8")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "soak_warm.py"),
+                          "777", "30", "3", "5151", "6401", "20", "2", "5152"],
+                         env=env, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "mismatches" in l]
+    assert len(lines) == 2, out.stdout[-2000:]
+    for l in lines:
+        assert " 0 mismatches" in l and "0 entries differ" in l, l
