@@ -136,6 +136,8 @@ def parse():
     ap.add_argument("--no-peaks", action="store_true", help="skip the peak microbenchmarks")
     ap.add_argument("--precision", choices=("double", "float"), default="double",
                     help="float: measure libcnmpc_f32.so (configs 2, 4, 5)")
+    ap.add_argument("--cpu-threads", type=int, default=None,
+                    help="threads of the CPU baseline (default: every core of this job's share)")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="units of the workload the CPU baseline processes per pass")
     a = ap.parse_args()
@@ -146,6 +148,31 @@ def parse():
     if a.steps is None:
         a.steps = {1: 200, 2: 20, 4: 10, 5: 20}[a.config]
     return a
+
+
+def host_cores(requested=None):
+    """Threads the CPU baseline runs on, and what the host offers.
+
+    The baseline uses every core this process may use: the scheduler affinity,
+    cut to the job's CPU share where the launcher states one (OMP_NUM_THREADS:
+    a one-GPU share of a many-GPU host exports its core count that way while the
+    affinity mask still shows the whole machine).  --cpu-threads overrides."""
+    avail = len(os.sched_getaffinity(0))
+    share = None
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", ""))
+    except ValueError:
+        pass
+    threads = requested or (min(avail, share) if share and share > 0 else avail)
+    model = None
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                model = l.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return max(1, threads), dict(cores_available=avail, cpu_share=share, cpu_model=model)
 
 
 def percentile(sorted_ms, q):
@@ -166,13 +193,43 @@ def measure_peaks(device):
     return out
 
 
+def traffic_file(tag):
+    """The PMC traffic summary of this workload: profiles/traffic_<tag>.json, which
+    tools/pmc_traffic.py rewrites whenever the counters are collected again."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
+    return path if os.path.exists(path) else None
+
+
+def traffic_source(path):
+    """File name plus what pins its contents: the library sources' hash recorded in it
+    when it was collected, and whether that still is the hash of the sources here."""
+    rel = os.path.relpath(path, ROOT)
+    j = json.load(open(path))
+    then = j.get("kernel_sources_sha1")
+    now = kernel_sources_sha1()
+    return dict(file=rel, collected_on_sources=then, sources_now=now,
+                stale=(then != now) if then else None)
+
+
+def kernel_sources_sha1():
+    """One hash over the library's kernel sources, the thing PMC counters go stale against."""
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "nmpc_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def load_traffic(tag, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this
     workload (tools/pmc_traffic.py), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % tag)
+    path = traffic_file(tag)
     if REAL["name"] != "f64":       # the counters were collected on the double-precision library
         return None
-    if os.path.exists(path):
+    if path:
         return json.load(open(path)).get("bytes_per_launch", {}).get(kernel)
     return None
 
@@ -182,8 +239,8 @@ def whole_step_traffic(tag, ms_per_step, peaks):
     x launches per step of every kernel in it) over the measured step time: what
     the path as a whole takes from the memory system, next to the one kernel the
     roofline entry prices."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % tag)
-    if REAL["name"] != "f64" or not os.path.exists(path):
+    path = traffic_file(tag)
+    if REAL["name"] != "f64" or not path:
         return None
     j = json.load(open(path))
     per, n = j.get("bytes_per_launch", {}), j.get("launches", {})
@@ -191,7 +248,7 @@ def whole_step_traffic(tag, ms_per_step, peaks):
     total = sum(per[k] * n.get(k, 0) for k in per) / steps
     gbps = total / 1e9 / (ms_per_step / 1e3)
     out = dict(traffic=round(total), GBps=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBS, 5),
-               source="profiles/r02_traffic_%s.json" % tag)
+               source=traffic_source(path))
     if peaks and peaks.get("hbm_triad_GBps"):
         out["frac_of_measured_hbm"] = round(gbps / peaks["hbm_triad_GBps"], 5)
     return out
@@ -314,6 +371,10 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     torch.cuda.synchronize(dev)
     u_all, st_all, it_all = (x.cpu().numpy() for x in res)
     u, st, it = out_u.cpu().numpy(), out_st.cpu().numpy(), out_it.cpu().numpy()
+    # NMPC_BENCH_DUMP=<file>: the gathered results of the last timed step, every
+    # rank's range in rank order, for a check against the CPU oracle (tests)
+    if rank == 0 and os.environ.get("NMPC_BENCH_DUMP"):
+        np.savez(os.environ["NMPC_BENCH_DUMP"], u=u_all, status=st_all, iterations=it_all)
 
     total_instances = B * world
     value = total_instances * a.steps / elapsed
@@ -423,7 +484,7 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import portdriver as P
-        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        cores, host = host_cores(a.cpu_threads)
         n = min(a.cpu_sample or 4096, B)
         cfg = S.setup_args()
         # repeat the sample until about 1.5 s of wall time (~20 core-seconds) has been timed
@@ -440,7 +501,7 @@ def run_cold(a, world, rank, local, dev, dist, peaks):
         cpu = dict(value=round(n * passes / secs, 1), unit="solves/s", cores=cores, kind="port",
                    sample="first %d instances of the same workload, cold solve each, %d passes, "
                           "%.2f s wall on %d threads" % (n, passes, secs, cores),
-                   gpu_results_identical=parity)
+                   gpu_results_identical=parity, **host)
 
     line = None
     if rank == 0:
@@ -530,7 +591,7 @@ def run_samples(a, world, rank, local, dev, dist, peaks):
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import portdriver as P
-        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        cores, host = host_cores(a.cpu_threads)
         m = min(a.cpu_sample or (1 << 18), n)
         secs, passes = 0.0, 0
         while secs < 1.5 and passes < 16:
@@ -543,7 +604,7 @@ def run_samples(a, world, rank, local, dev, dist, peaks):
                    kind="port",
                    sample="first %d samples of the same workload, %d passes, %.2f s wall on %d "
                           "threads" % (m, passes, secs, cores),
-                   gpu_results_identical=bool(same_bits(cj, gj) and same_bits(cr, gr)))
+                   gpu_results_identical=bool(same_bits(cj, gj) and same_bits(cr, gr)), **host)
     if rank != 0:
         return None
     return {
@@ -646,7 +707,7 @@ def run_single(a, local, dev, peaks):
                    p50_ms=round(percentile(clat, 0.5), 4), p99_ms=round(percentile(clat, 0.99), 4),
                    sample="the same %d control steps of the same controller, one thread, "
                           "through ctypes" % len(clat),
-                   gpu_results_identical=same)
+                   gpu_results_identical=same, **host_cores(1)[1])
     return {
         "metric": METRIC, "value": round(steps / elapsed, 1), "unit": "solves/s", "n_gpus": 1,
         "steps": steps, "warmup": a.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),

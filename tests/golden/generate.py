@@ -172,6 +172,48 @@ def gen_indefinite():
                  weights=dict(state_weights=[1, 1, 1, -1, -1, -1, 1, 1, 1, 1, 1, 1]), dump=True)
 
 
+def gen_reinit():
+    """A second nmpc_init in the middle of a run (ccs-c66x/cnmpc.c:872-948): it
+    rebuilds the stage QPs and the interval order from the weights and bounds of
+    that moment, but the multipliers, the stage vectors' history and the Newton
+    system are file statics that it does not clear (cnmpc.c:298, 801-870), so the
+    first solve after it starts from what the run before left.  Phase 1: the
+    default configuration, four control steps.  Phase 2: other weights and bounds,
+    init, another wind, another trajectory, four control steps."""
+    N, steps = 100, 4
+    d = S.make_batch(2, N, extra_steps=steps, seed=11, turn_start=(0.3, 3.0))
+    cfg1 = S.setup_args()
+    cfg2 = dict(state_weights=[2, 2, 2, 1, 1, 1, 3, 3, 12, 0.5, 0.5, 8], control_weights=[0.2, 8e2, 9e2],
+                terminal_weights=[1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1],
+                upper_control_bound=[0.9, 0.95, 0.9], lower_control_bound=[0.1, 0.05, 0.1])
+    r = Ref(N)
+    out = dict(horizon=np.int32(N), steps=np.int32(steps), refs=d["refs"], meas=d["meas"][:, :steps],
+               winds=d["wind"])
+    for ph, cfg in enumerate((cfg1, cfg2)):
+        for k, v in cfg.items():
+            out["%s_%d" % (k, ph)] = np.asarray(v, dtype=np.float64)
+    u = np.zeros((2, steps, 3))
+    status = np.zeros((2, steps), dtype=np.int32)
+    iters = np.zeros((2, steps), dtype=np.int32)
+    for ph, cfg in enumerate((cfg1, cfg2)):
+        r.setup(cfg["state_weights"], cfg["control_weights"], cfg["terminal_weights"],
+                cfg["upper_control_bound"], cfg["lower_control_bound"])
+        r.init()
+        r.set_wind(d["wind"][ph])
+        for i in range(N + 1):
+            r.set_reference(d["refs"][ph, i], i)
+        out["loaded_%d" % ph] = r.stages()
+        for k in range(steps):
+            r.feedback(d["meas"][ph, k])
+            u[ph, k], status[ph, k] = r.controls()
+            iters[ph, k] = r.num_iter()
+            r.update_horizon(d["refs"][ph, N + 1 + k])
+        out["final_stages_%d" % ph] = r.stages()
+        out["final_globals_%d" % ph] = r.globals_()
+    save("seq_reinit", u=u, status=status, iters=iters, **out)
+    print("    status", status.tolist(), "iters", iters.tolist())
+
+
 def gen_single_precision():
     """The reference in its shipped single-precision configuration."""
     gen_model("float", "model_f32")
@@ -212,7 +254,7 @@ def gen_long_horizon():
 if __name__ == "__main__":
     import sys
     parts = dict(model=gen_model, linearise=gen_linearise, sequences=gen_sequences,
-                 indefinite=gen_indefinite, long_horizon=gen_long_horizon,
+                 indefinite=gen_indefinite, reinit=gen_reinit, long_horizon=gen_long_horizon,
                  single_precision=gen_single_precision)
     for name in (sys.argv[1:] or list(parts)):      # no argument: everything
         parts[name]()

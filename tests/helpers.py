@@ -98,6 +98,77 @@ def drive_gpu_batch(gs, dump=False):
     return out
 
 
+def drive_reinit(ctrl, g):
+    """Replay the seq_reinit fixture (two initialisations of one controller in a
+    row, see tests/golden/generate.py) through `ctrl`, an object with the
+    surface of portdriver.Port, comparing as it goes."""
+    N, steps = int(g["horizon"]), int(g["steps"])
+    for ph in range(2):
+        ctrl.setup(g["state_weights_%d" % ph], g["control_weights_%d" % ph], g["terminal_weights_%d" % ph],
+                   g["upper_control_bound_%d" % ph], g["lower_control_bound_%d" % ph])
+        ctrl.init()
+        ctrl.set_wind(g["winds"][ph])
+        for i in range(N + 1):
+            ctrl.set_reference(g["refs"][ph, i], i)
+        assert_same(ctrl.stages(), g["loaded_%d" % ph], "stage records after loading, phase %d" % ph)
+        for k in range(steps):
+            ctrl.feedback(g["meas"][ph, k])
+            u, st = ctrl.controls()
+            what = "phase %d step %d" % (ph, k)
+            assert st == g["status"][ph, k], what
+            assert ctrl.num_iter() == g["iters"][ph, k], what
+            assert_same(u, g["u"][ph, k], "controls, " + what)
+            ctrl.update_horizon(g["refs"][ph, N + 1 + k])
+        assert_same(ctrl.stages(), g["final_stages_%d" % ph], "final stage records, phase %d" % ph)
+        assert_same(ctrl.globals_(), g["final_globals_%d" % ph], "final solver state, phase %d" % ph)
+
+
+class BatchAsController:
+    """One instance of a nmpc_amd.batch.Batch of identical instances behind the
+    surface of portdriver.Port."""
+
+    def __init__(self, horizon, copies=1, watch=0):
+        from nmpc_amd.batch import Batch
+        self.bt, self.B, self.b = Batch(copies, horizon), copies, watch
+
+    def _all(self, v):
+        return np.repeat(np.asarray(v, dtype=self.bt.dtype)[None], self.B, axis=0)
+
+    def setup(self, state_w, control_w, terminal_w, upper, lower):
+        self.bt.setup(state_w, control_w, terminal_w, upper, lower)
+
+    def init(self):
+        self.bt.initialise_horizon()
+
+    def set_wind(self, w):
+        self.bt.set_wind_velocity(self._all(w))
+
+    def set_reference(self, point, i):
+        self.bt.set_reference(self._all(point)[:, None, :], first=i)
+
+    def feedback(self, meas):
+        self.bt.solve(self._all(meas))
+        self.last = self.bt.get_controls()
+
+    def controls(self):
+        return self.last[0][self.b], int(self.last[1][self.b])
+
+    def num_iter(self):
+        return int(self.last[2][self.b])
+
+    def update_horizon(self, point):
+        self.bt.update_horizon(self._all(point))
+
+    def stages(self):
+        return self.bt.stages(self.b)
+
+    def globals_(self):
+        return self.bt.globals_(self.b)
+
+    def close(self):
+        self.bt.close()
+
+
 def same_bits(a, b):
     """Element-wise: the same bit pattern (so -0.0 differs from +0.0), or both NaN
     (x86 and gfx950 produce default NaNs of opposite sign)."""

@@ -364,6 +364,22 @@ def test_piecewise_reference_loading_and_reset():
     bt0.close()
 
 
+@pytest.mark.parametrize("copies,watch", [(1, 0), (5, 3)])
+def test_second_initialisation_keeps_solver_state(copies, watch):
+    """init -> control steps -> init with other weights and bounds -> control
+    steps: the second nmpc_init rebuilds the stage QPs and the interval order
+    but keeps multipliers, stage history and Newton system
+    (ccs-c66x/cnmpc.c:298, 801-870).  Against the sequence recorded from the
+    compiled reference, full state after loading and at the end of both phases
+    (the library's ring offsets, postponed clears and postponed re-staging all
+    cross the second init here)."""
+    from helpers import BatchAsController, drive_reinit
+    g = golden("seq_reinit")
+    ctrl = BatchAsController(int(g["horizon"]), copies, watch)
+    drive_reinit(ctrl, g)
+    ctrl.close()
+
+
 def test_closed_loop_with_device_plant(port_built):
     """Controllers and simulated vehicles both on the GPU: feedback on the plant
     state, one RK4 step of the plant under the returned controls and a wind

@@ -159,3 +159,22 @@ def test_cheaper_integrators_have_their_order(port_built, integrator, order):
             ratios.append(e1 / e2)
     r = float(np.median(ratios))
     assert 0.75 * 2 ** (order + 1) < r < 1.25 * 2 ** (order + 1), (integrator, r)
+
+
+def test_second_initialisation_keeps_solver_state(port_built):
+    """nmpc_init in the middle of a run rebuilds the stage QPs but clears neither
+    the multipliers nor the Newton system (ccs-c66x/cnmpc.c:298, 801-870): the port
+    against the sequence recorded from the compiled reference, stage records and
+    solver state after loading and at the end of either phase included."""
+    from helpers import drive_reinit
+    g = golden("seq_reinit")
+    drive_reinit(port_built.Port(int(g["horizon"])), g)
+    # the second phase's first solves do depend on what the first phase left
+    fresh = port_built.Port(int(g["horizon"]))
+    fresh.setup(g["state_weights_1"], g["control_weights_1"], g["terminal_weights_1"],
+                g["upper_control_bound_1"], g["lower_control_bound_1"])
+    fresh.init()
+    fresh.set_wind(g["winds"][1])
+    for i in range(int(g["horizon"]) + 1):
+        fresh.set_reference(g["refs"][1, i], i)
+    assert not np.array_equal(fresh.stages(), g["loaded_1"])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a profiling
-workload into profiles/r02_traffic_<tag>.json: mean HBM bytes per launch of
-every nmpc kernel.
+workload into gpurun_out/traffic_<tag>.json (copy it to profiles/, where bench.py
+looks for it): mean HBM bytes per launch of every nmpc kernel, with a hash of the
+library sources the counters were collected on.
 
     python tools/pmc_traffic.py <fetch counter_collection.csv> <write ...csv> <tag> <workload text>
 
@@ -56,8 +57,17 @@ def main():
         out["read_bytes_per_launch"][k] = round(r)
         out["write_bytes_per_launch"][k] = round(w)
         out["launches"][k] = len(fetch.get(name, []))
-    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       "gpurun_out", "r02_traffic_%s.json" % tag)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(root, "nmpc_amd", "csrc")
+    for name in sorted(os.listdir(src)):      # the same hash as bench.py's kernel_sources_sha1
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    out["kernel_sources_sha1"] = h.hexdigest()[:12]
+    dst = os.path.join(root, "gpurun_out", "traffic_%s.json" % tag)
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print(tag, json.dumps(out["bytes_per_launch"]))
