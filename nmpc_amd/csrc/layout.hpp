@@ -128,6 +128,7 @@ struct BatchView {
     // [listRange[0], listRange[1]) of list, or all of [b0, b0 + nb) when list is null.
     const int* list;
     const int* listRange;
+    int listPart;       // which part of the list the range is: 0 whole, 1 long sweeps, 2 the rest
     real_t H[15];       // regular-stage Hessian diagonal as the solver sees it
     real_t Ht[12];      // terminal-stage Hessian diagonal
     real_t lb[3], ub[3];

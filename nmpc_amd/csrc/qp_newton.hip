@@ -5,6 +5,7 @@
 //                     two substitutions (dual_qp.c:601-698, 817-908, 993-1055)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <utility>
 
@@ -485,6 +486,398 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
     if (live && t == 0) I.sc->dlNorm2 = norm2;
 }
 
+
+#ifndef NMPC_SINGLE_PRECISION
+// ------------------------------------------------------------------------
+// Team form of the bottom-up sweep: the four wavefronts of a workgroup, one per
+// SIMD of a CU, work on the same four instances.  A factorised block is a chain
+// of some 420 dependent operations (per row of the diagonal block: up to 23
+// ordered subtractions, the pivot's root and reciprocal, a quotient) inside about
+// 1 800 instructions, and a wavefront that is alone on its SIMD issues one
+// instruction every five cycles: the instructions that are not the chain cost
+// more than the chain does.  Where SIMDs are idle anyway (few instances with long
+// sweeps, or a small batch) they take those instructions over:
+//
+//   wave 0 (kFactor)   the diagonal block's rows: the chain and the products of
+//                      its own rows (dual_qp.c:835-887)
+//   wave 1 (kSub)      the sub-diagonal block's rows (dual_qp.c:889-901), one row
+//                      behind
+//   wave 2 (kProd)     the products of the finished sub-diagonal rows that the
+//                      block above will subtract (dual_qp.c:845-847, 879-883),
+//                      two rows behind
+//   wave 3 (kSubst)    the bottom-up substitution (dual_qp.c:1003-1026) and the
+//                      stores of the factor, one block behind
+//
+// Lane i of every wavefront works on the same (instance, column) pair, so a value
+// passes from wave to wave through one LDS word per lane.  The wavefronts run in
+// lock step, thirteen workgroup barriers per block (one per row and one for the
+// hand-over of the last row's products); a row is published by the barrier that
+// follows its write, and wave 0 reaches that barrier a few instructions into its
+// next row, so that it never waits for its own LDS write.
+//
+// Every value is computed by the same operations in the same order as in
+// backward_pass, by whichever wavefront.  What the team does not handle itself
+// -- a failed pivot, a pivot root whose significand is all ones -- makes it stop
+// (`bail`); the caller then repeats the sweep with backward_pass, which is
+// possible because everything the team has stored by then is what that sweep
+// stores again.
+namespace team {
+
+constexpr int kWaves = 4;
+constexpr int kFactor = 0, kSub = 1, kProd = 2, kSubst = 3;
+constexpr int kTri = NX * (NX + 1) / 2;     // (row, column <= row) pairs of a diagonal block
+constexpr int kProducts = kGroupsPerWave * kTri * NX;
+constexpr int kMaxInstances = 4 * 256;      // beyond one team per CU the one-wavefront form has the higher throughput
+
+struct Shared {
+    pair_a frow[2][NX][kWave];      // by block parity: row of the diagonal block's factor {lane's entry, RN(1 / pivot)}
+    real_t brow[2][NX][kWave];      // row of the sub-diagonal block's factor
+    // Products Ls[l][t] * Ls[l][jj] of the block below, by block parity; the twelve
+    // l of (row jj, column t <= jj) of a group are adjacent (see c_slot).  Lanes
+    // right of the diagonal write theirs into the spare words at the end.
+    __attribute__((aligned(16))) real_t cprod[2][kProducts + kWave + NX];
+    real_t minDiag[kWave];
+    int bail;
+};
+
+// First of the twelve products of (row JJ, column t <= JJ) of group g.
+template <int JJ>
+NMPC_DEV int c_slot(int g, int t) {
+    constexpr int T = JJ * (JJ + 1) / 2;
+    return (T * kGroupsPerWave + g * (JJ + 1) + t) * NX;
+}
+// Per lane and row: where the lane reads its twelve products (any valid place
+// right of the diagonal, where nothing uses them) and where it writes them.
+struct Slots { int at[NX]; };
+template <int... JJ>
+NMPC_DEV Slots read_slots(int g, int t, std::integer_sequence<int, JJ...>) {
+    return Slots{{c_slot<JJ>(g, t < JJ ? t : JJ)...}};
+}
+template <int... JJ>
+NMPC_DEV Slots write_slots(int g, int t, int lane, std::integer_sequence<int, JJ...>) {
+    return Slots{{(t <= JJ ? c_slot<JJ>(g, t) : kProducts + lane)...}};
+}
+
+// A row is published to the other wavefronts by the barrier behind its write.
+NMPC_DEV void team_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+NMPC_DEV void read_products(const real_t* at, real_t (&cc)[NX]) {
+    const pair_a* p = (const pair_a*)at;
+#pragma unroll
+    for (int l = 0; l < NX / 2; l++) {
+        const pair_a v = p[l];
+        cc[2 * l] = v.x;
+        cc[2 * l + 1] = v.y;
+    }
+}
+
+// Products of row R of a sub-diagonal block, ls this lane's entry, with its entries
+// in the columns FIRST + J...: what row FIRST + J of the block above subtracts as
+// its term R.
+template <int JJ>
+NMPC_DEV void row_product(real_t* cbuf, const Slots& w, real_t ls, int R) {
+    cbuf[w.at[JJ] + R] = ls * row_bcast<JJ>(ls);
+}
+template <int FIRST, int... J>
+NMPC_DEV void row_products(real_t* cbuf, const Slots& w, real_t ls, int R, std::integer_sequence<int, J...>) {
+    (row_product<FIRST + J>(cbuf, w, ls, R), ...);
+}
+
+// ---- wave 0 ----------------------------------------------------------------
+// Item I of the products of row JJ with the rows below it: L[l][t] * L[l][JJ], l = JJ + 2 + I.
+template <int JJ, int I>
+NMPC_DEV void make_a(real_t (&qa)[NX], const real_t (&L)[NX]) {
+    if constexpr (JJ >= 0 && JJ + 2 + I < NX) {
+        constexpr int l = JJ + 2 + I;
+        qa[l] = L[l] * row_bcast<JJ>(L[l]);
+        NMPC_PIN(qa[l]);
+    }
+}
+
+template <int JJ, int S>
+NMPC_DEV void factor_chain_step(real_t& sum, const real_t (&pa)[NX], real_t (&qa)[NX],
+                                const real_t (&cc)[NX], const real_t (&L)[NX]) {
+    constexpr int nA = JJ + 2 < NX ? NX - 2 - JJ : 0;
+    if constexpr (S < nA) sum -= pa[JJ + 2 + S];
+    else sum -= cc[S - nA];
+    NMPC_PIN(sum);
+    make_a<JJ - 1, S>(qa, L);
+}
+
+template <int JJ, int... S>
+NMPC_DEV void factor_chain(real_t& sum, const real_t (&pa)[NX], real_t (&qa)[NX], const real_t (&cc)[NX],
+                           const real_t (&L)[NX], std::integer_sequence<int, S...>) {
+    (factor_chain_step<JJ, S>(sum, pa, qa, cc, L), ...);
+}
+
+// Row JJ of the diagonal block of block row k: on entry cc holds the products of
+// the block below for this row, pa this row's products with the rows below it;
+// on exit they hold those of row JJ - 1.
+template <int JJ>
+NMPC_DEV void factor_row(Shared& sh, int par, const real_t* cbuf, const Slots& rd, const real_t (&Hd)[NX],
+                         real_t (&L)[NX], real_t (&pa)[NX], real_t (&cc)[NX], int t, int lane,
+                         int& failCol, uint32_t& ones) {
+    constexpr int nA = JJ + 2 < NX ? NX - 2 - JJ : 0;
+    real_t sum = Hd[JJ];
+    if constexpr (JJ + 1 < NX) {
+        sum -= L[JJ + 1] * row_bcast<JJ>(L[JJ + 1]);        // the row just finished
+        NMPC_PIN(sum);
+        team_barrier();                                     // ... which this publishes
+    }
+    real_t cn[NX];
+    if constexpr (JJ > 0) read_products(cbuf + rd.at[JJ - 1], cn);
+    real_t qa[NX];
+    factor_chain<JJ>(sum, pa, qa, cc, L, std::make_integer_sequence<int, nA + NX>{});
+    const real_t piv = row_bcast<JJ>(sum);
+    if (failCol < 0 && piv < 1.e2 * kEqTol) failCol = JJ;
+    const Pivot pv = root_and_reciprocal(piv);
+    const real_t ld = divide<true>(sum, pv);
+    const uint32_t lo = (uint32_t)__double_as_longlong(pv.d);
+    ones = lo > ones ? lo : ones;
+    L[JJ] = (t == JJ) ? pv.d : ld;
+    pair_a out;
+    out.x = L[JJ];
+    out.y = pv.y;
+    sh.frow[par][JJ][lane] = out;
+    if constexpr (JJ > 0) {
+#pragma unroll
+        for (int l = JJ + 1; l < NX; l++) pa[l] = qa[l];
+#pragma unroll
+        for (int l = 0; l < NX; l++) cc[l] = cn[l];
+    }
+}
+
+template <int... R>
+NMPC_DEV void factor_rows(Shared& sh, int par, const real_t* cbuf, const Slots& rd, const real_t (&Hd)[NX],
+                          real_t (&L)[NX], int t, int lane, int& failCol, uint32_t& ones,
+                          std::integer_sequence<int, R...>) {
+    real_t pa[NX], cc[NX];
+    read_products(cbuf + rd.at[NX - 1], cc);
+    (factor_row<NX - 1 - R>(sh, par, cbuf, rd, Hd, L, pa, cc, t, lane, failCol, ones), ...);
+}
+
+// ---- wave 1 ----------------------------------------------------------------
+// Row R of the sub-diagonal block once row R of the diagonal block is published:
+// its quotient, then the chain of row R - 1 up to the division.  sub holds the
+// numerator of row R on entry and that of row R - 1 on exit.  The last row's
+// products for the two rows the block above starts with are made here as well:
+// wave 0 waits for them.
+template <int R>
+NMPC_DEV void sub_row(Shared& sh, int par, real_t* cbuf, const Slots& wr, bool fromHess, const real_t (&Hs)[NX],
+                      real_t (&L)[NX], real_t (&Ls)[NX], real_t& sub, int lane) {
+    NMPC_PIN(sub);                          // the numerator is ready before the pivot is
+    team_barrier();                         // row R of the diagonal block is there
+    const pair_a in = sh.frow[par][R][lane];
+    L[R] = in.x;
+    const Pivot pv{row_bcast<R>(in.x), in.y};
+    const real_t ls = divide<true>(sub, pv);
+    Ls[R] = fromHess ? ls : Ls[R];          // (else Ls holds the stored factor)
+    sh.brow[par][R][lane] = Ls[R];
+    if constexpr (R > 0) {
+        sub = Hs[R - 1];
+#pragma unroll
+        for (int l = R; l < NX; l++) sub -= Ls[l] * row_bcast<R - 1>(L[l]);
+    } else {
+        row_products<NX - 2>(cbuf, wr, Ls[0], 0, std::make_integer_sequence<int, 2>{});
+    }
+}
+
+template <int... R>
+NMPC_DEV void sub_rows(Shared& sh, int par, real_t* cbuf, const Slots& wr, bool fromHess, const real_t (&Hs)[NX],
+                       real_t (&L)[NX], real_t (&Ls)[NX], int lane, std::integer_sequence<int, R...>) {
+    real_t sub = Hs[NX - 1];
+    (sub_row<NX - 1 - R>(sh, par, cbuf, wr, fromHess, Hs, L, Ls, sub, lane), ...);
+}
+
+// ---- wave 2 ----------------------------------------------------------------
+// Barrier b = 1 .. 13 of a slot.  Row R of block k's sub-diagonal block is written
+// between the barriers 13 - R and 14 - R, so it is read behind barrier 14 - R: rows
+// 11 .. 1 behind the barriers 3 .. 13 of their own slot, row 0 behind barrier 1 of
+// the next (its products for the first two rows of the block above are wave 1's).
+template <int BAR>
+NMPC_DEV void prod_step(Shared& sh, int parK, int parM, const Slots& wr, bool haveK, bool haveM, int lane) {
+    team_barrier();
+    if constexpr (BAR == 1) {
+        if (haveM) row_products<0>(sh.cprod[parM], wr, sh.brow[parM][0][lane], 0, std::make_integer_sequence<int, NX - 2>{});
+    } else if constexpr (BAR >= 3) {
+        constexpr int R = 14 - BAR;
+        if (haveK) row_products<0>(sh.cprod[parK], wr, sh.brow[parK][R][lane], R, std::make_integer_sequence<int, NX>{});
+    }
+}
+template <int... BAR>
+NMPC_DEV void prod_steps(Shared& sh, int parK, int parM, const Slots& wr, bool haveK, bool haveM, int lane,
+                         std::integer_sequence<int, BAR...>) {
+    (prod_step<1 + BAR>(sh, parK, parM, wr, haveK, haveM, lane), ...);
+}
+
+// ---- wave 3 ----------------------------------------------------------------
+// Step R of a slot: row R of the substitution of block m and the stores of row R
+// of its factor.
+template <bool FAST, int R>
+NMPC_DEV void subst_row(bool storeM, bool storeSub, real_t* cholRow, real_t (&xk)[NX], real_t& mine,
+                        const real_t (&L)[NX], const real_t (&Ls)[NX], const real_t (&pn)[NX], real_t gm,
+                        const Pivot& dd, int t) {
+    team_barrier();
+    backsolve_row<FAST, R>(xk, mine, L, pn, gm, dd, t);
+    if (storeM) {
+        if (R >= t) cholRow[kCholDiagRow[R] + t] = L[R];
+        if (storeSub) cholRow[NX * R + t] = Ls[R];
+    }
+}
+
+template <bool FAST, int... R>
+NMPC_DEV void subst_rows(bool storeM, bool storeSub, real_t* cholRow, real_t (&xk)[NX], real_t& mine,
+                         const real_t (&L)[NX], const real_t (&Ls)[NX], const real_t (&pn)[NX], real_t gm,
+                         const Pivot& dd, int t, std::integer_sequence<int, R...>) {
+    (subst_row<FAST, NX - 1 - R>(storeM, storeSub, cholRow, xk, mine, L, Ls, pn, gm, dd, t), ...);
+}
+
+NMPC_DEV void idle_slot() {
+#pragma unroll
+    for (int r = 0; r < NX; r++) team_barrier();
+}
+
+// The sweep.  Slot i = 0 .. N: waves 0 to 2 work on block k = N - 1 - i (none in
+// the last slot), wave 3 on block m = k + 1 (none in the first).  Returns true
+// when the sweep was given up (`bail`); minDiag as backward_pass leaves it.
+NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bool active, int role,
+                    int lane, real_t& minDiag) {
+    const int N = v.N;
+    const int g = lane >> 4, t = lane & 15;
+    const bool col = t < NX;
+    const int tc = col ? t : 0;
+    const int maxStart = wave_max(active ? start : -1);     // blocks k <= maxStart are factorised by all
+    // the block below the last one is empty: its products are +0, and x - (+0) = x
+    {
+        real_t* c0 = sh.cprod[N & 1];
+        for (int i = threadIdx.x; i < kProducts; i += kWaves * kWave) c0[i] = 0.;
+        if (threadIdx.x == 0) sh.bail = 0;
+    }
+    __syncthreads();
+
+    const Slots slots = role == kFactor ? read_slots(g, tc, Seq12{}) : write_slots(g, t, lane, Seq12{});
+    real_t L[NX], Ls[NX];           // wave 0: L; wave 1: both; wave 3: those of block m
+    real_t nA[NX], ng = 0.;         // the column fetched for the next slot (Hessian or stored factor)
+    real_t xk[NX], pn[NX];          // wave 3
+#pragma unroll
+    for (int l = 0; l < NX; l++) { L[l] = 0.; Ls[l] = 0.; nA[l] = 0.; xk[l] = 0.; pn[l] = 0.; }
+
+    // Column tc of block row kk: from the Newton Hessian when the block is
+    // factorised, from the stored factor otherwise (one load per value, its place
+    // chosen between the two layouts).  Wave 0 takes the diagonal block, wave 1
+    // the sub-diagonal block.
+    auto fetch = [&](int kk) {
+        if (kk < 0 || !active) return;
+        const bool fromH = kk <= maxStart;
+        const real_t* row = (fromH ? I.hess + (size_t)kk * (2 * NX * NX) : I.chol + (size_t)kk * kCholRow) + tc;
+        if (role == kFactor) {
+#pragma unroll
+            for (int l = 0; l < NX; l++) nA[l] = row[fromH ? l * 2 * NX + NX : kCholDiagRow[l]];
+        } else {
+#pragma unroll
+            for (int l = 0; l < NX; l++) nA[l] = row[fromH ? l * 2 * NX : NX * l];
+        }
+    };
+    if (role == kSubst) { if (active) ng = I.grad[(N - 1) * NX + tc]; }
+    else if (role != kProd) fetch(N - 1);
+
+    bool bail = false;
+    for (int i = 0; i <= N && !bail; ++i) {
+        const int k = N - 1 - i, m = k + 1;
+        const bool haveK = k >= 0, haveM = m <= N - 1;
+        const bool fromHess = haveK && k <= maxStart;
+        const int parK = k & 1, parM = m & 1;
+        if (role == kFactor) {
+            real_t A[NX];
+#pragma unroll
+            for (int l = 0; l < NX; l++) A[l] = nA[l];
+            fetch(k - 1);
+            team_barrier();         // the products of the block below are complete
+            if (fromHess) {
+                int failCol = -1;
+                uint32_t ones = 0;
+                factor_rows(sh, parK, sh.cprod[parM], slots, A, L, t, lane, failCol, ones, Seq12{});
+                const bool failed = active && k <= start && failCol >= 0;
+                bool giveUp = __any(failed || (active && ones == 0xffffffffu));
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: give up half-way through every sweep
+                giveUp = giveUp || k == N / 2;
+#endif
+                if (giveUp && lane == 0) sh.bail = 1;
+                team_barrier();     // row 0
+            } else {
+                if (haveK) {
+#pragma unroll
+                    for (int l = 0; l < NX; l++) {
+                        pair_a out;
+                        out.x = A[l];
+                        out.y = 0.;
+                        sh.frow[parK][l][lane] = out;
+                    }
+                }
+                idle_slot();
+            }
+        } else if (role == kSub) {
+            real_t A[NX];
+#pragma unroll
+            for (int l = 0; l < NX; l++) A[l] = nA[l];
+            fetch(k - 1);
+            team_barrier();
+            if (haveK) {
+                if (!fromHess) {
+#pragma unroll
+                    for (int l = 0; l < NX; l++) Ls[l] = A[l];
+                }
+                sub_rows(sh, parK, sh.cprod[parK], slots, fromHess, A, L, Ls, lane, Seq12{});
+            } else {
+                idle_slot();
+            }
+        } else if (role == kProd) {
+            prod_steps(sh, parK, parM, slots, haveK, haveM, lane, std::make_integer_sequence<int, NX + 1>{});
+        } else {
+            const real_t gm = ng;
+            if (haveK && active) ng = I.grad[k * NX + tc];
+            team_barrier();
+            if (haveM) {
+                // block m is complete: the lane's column of both blocks, its own pivot
+#pragma unroll
+                for (int l = 0; l < NX; l++) {
+                    L[l] = sh.frow[parM][l][lane].x;
+                    Ls[l] = sh.brow[parM][l][lane];
+                }
+                const pair_a own = sh.frow[parM][tc][lane];
+                const bool mFromHess = m <= maxStart;
+                Pivot dd;
+                dd.d = active ? own.x : 1.;
+                dd.y = mFromHess ? own.y : 1.0 / dd.d;
+                if (col && minDiag > dd.d) minDiag = dd.d;
+                const bool storeM = active && col && m <= start;
+                real_t* cholRow = I.chol + (size_t)m * kCholRow;
+                real_t mine = 0.;
+                if (!mFromHess && __any(plain_division_needed(dd.d)))
+                    subst_rows<false>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
+                else
+                    subst_rows<true>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
+                // into scratch: the step itself is only written once the factor is known to be good
+                if (active && col) I.tmp[m * NX + t] = mine;
+#pragma unroll
+                for (int j = 0; j < NX; j++) pn[j] = Ls[j] * xk[j];
+            } else {
+                idle_slot();
+            }
+        }
+        bail = sh.bail != 0;        // read before this wavefront's next barrier, written before the last one
+    }
+    if (role == kSubst) sh.minDiag[lane] = minDiag;
+    __syncthreads();                // wave 3's stores of the factor and of the scratch are done
+    if (role == kFactor) minDiag = sh.minDiag[lane];
+    return bail;
+}
+
+}  // namespace team
+#endif  // NMPC_SINGLE_PRECISION
+
 }  // namespace
 
 // dual_qp.c:601-698 followed by :993-1055
@@ -501,12 +894,23 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 __device__ unsigned long long g_solve_stats[16];
 #endif
 
+// Does the team form (k_newton_solve_team, launched in front of this kernel) take a
+// listed launch?  Only a list short enough for one team per CU.
+NMPC_DEV bool team_takes_list(const BatchView& v) {
+#ifndef NMPC_SINGLE_PRECISION
+    return v.list && v.listRange[1] - v.listRange[0] <= team::kMaxInstances;
+#else
+    return false;
+#endif
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-void k_newton_solve(BatchView v) {
+void k_newton_solve(BatchView v, int teamBeside) {
 #ifdef NMPC_SOLVE_STATS
     const long long c0 = clock64();
 #endif
+    if (teamBeside && team_takes_list(v)) return;
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
     const int first = blockIdx.x * kGroupsPerWave;
     const int b0 = launch_instance(v, first);
@@ -564,6 +968,74 @@ void k_newton_solve(BatchView v) {
     }
 #endif
 }
+
+#ifndef NMPC_SINGLE_PRECISION
+// The same solve with the first bottom-up sweep run by a team of four wavefronts
+// (namespace team); regularised second sweeps, sweeps the team gives up, and the
+// top-down substitution are wave 0's alone, through the code of k_newton_solve.
+__global__ __launch_bounds__(team::kWaves * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_newton_solve_team(BatchView v) {
+    __shared__ team::Shared sh;
+#ifdef NMPC_SOLVE_STATS
+    const long long c0 = clock64();
+#endif
+    if (v.list && !team_takes_list(v)) return;      // k_newton_solve, launched behind, takes it
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1), g = lane >> 4, t = lane & 15;
+    const int first = blockIdx.x * kGroupsPerWave;
+    const int b0 = launch_instance(v, first);
+    if (b0 < 0) return;
+    if (role == team::kFactor) __builtin_amdgcn_s_setprio(3);
+    const int bg = launch_instance(v, first + g);
+    const bool have = bg >= 0;
+    const int b = have ? bg : b0;
+    Inst I = instance(v, b);
+    bool live = have && (I.sc->status == ST_RUNNING);
+    if (!__any(live)) return;
+    const int N = v.N;
+    const int last = I.sc->last;
+    const int start = (live && last >= 0) ? (last < N - 1 ? last : N - 1) : -1;
+
+    real_t minDiag = kInfty;
+    const bool gaveUp = team::sweep(sh, v, I, start, live, role, lane, minDiag);
+    if (role != team::kFactor) return;
+    int st = ST_OK;
+    if (gaveUp) {
+        minDiag = kInfty;
+        st = backward_pass<false>(v, I, start, live, t, minDiag);
+    }
+    // regularisation and second sweep as in k_newton_solve (dual_qp.c:601-698)
+    minDiag = group_min(minDiag);
+    const bool needReg = live && (st == ST_DIV_ZERO || minDiag < kDiagRegTol);
+    if (__any(needReg)) {
+        if (needReg && t < NX)
+            for (int k = 0; k < N; k++) HS(I.hess, k, 0, t, t) += kRegParam;
+        if (needReg && t == 0) I.sc->regularized = 1;
+        real_t unused = kInfty;
+        st = backward_pass<false>(v, I, N - 1, needReg, t, unused);
+        if (needReg && st != ST_OK) {
+            if (t == 0) I.sc->status = st;
+            live = false;
+        }
+    }
+    if (!__any(live)) return;
+#ifdef NMPC_SOLVE_STATS
+    const long long c1 = clock64();
+#endif
+    forward_pass(v, I, live, t);
+#ifdef NMPC_SOLVE_STATS
+    const long long c2 = clock64();
+    if (lane == 0) {
+        const int part = (v.list && v.listRange[0] > 0) ? 8 : 0;
+        atomicAdd(&g_solve_stats[part + 0], 1ull);
+        atomicAdd(&g_solve_stats[part + 1], (unsigned long long)(c1 - c0));
+        atomicAdd(&g_solve_stats[part + 2], (unsigned long long)(c2 - c1));
+        atomicAdd(&g_solve_stats[part + 3], (unsigned long long)(wave_max(start) + 1));
+        atomicMax(&g_solve_stats[part + 4], (unsigned long long)(c1 - c0));
+        atomicMax(&g_solve_stats[part + 5], (unsigned long long)(c2 - c1));
+    }
+#endif
+}
+#endif  // NMPC_SINGLE_PRECISION
 
 // ------------------------------------------------------------------------
 // Instance list of a large grid's Newton solve: a counting sort of the running
@@ -670,6 +1142,7 @@ BatchView solve_list_view(const BatchView& v, unsigned epoch, int part) {
     const int* ctr = v.solveCount + (epoch & 1) * kSolveListStride;
     w.list = v.solveList;
     w.listRange = ctr + (part == 1 ? kSolveRangeLong : part == 2 ? kSolveRangeShort : kSolveRangeAll);
+    w.listPart = part;
     if (part == 2 && v.tailCount) {
         w.tailCount = v.tailCount + 16;
         w.tailList = v.tailList + 2 * (size_t)v.B;
@@ -677,10 +1150,34 @@ BatchView solve_list_view(const BatchView& v, unsigned epoch, int part) {
     return w;
 }
 
+// The team form pays where it leaves no SIMD short of work: an unlisted launch of at
+// most one team per CU, or the long-sweep part of a two-part iteration (whose
+// length only the device knows: both kernels are launched and the list's length
+// decides which of them works).  Off unless NMPC_TEAM is set.
+static bool team_wanted(const BatchView& v) {
+#ifdef NMPC_SINGLE_PRECISION
+    return false;
+#else
+    static const bool off = getenv("NMPC_TEAM") == nullptr;     // opt-in while it is being measured
+    if (off || newton_solve_two_waves(v)) return false;
+    if (v.list) return v.listPart == 1;
+    return v.nb <= team::kMaxInstances;
+#endif
+}
+
 void launch_newton_solve(const BatchView& v, hipStream_t s) {
     const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
-    if (newton_solve_two_waves(v)) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
-    else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);
+    int teamBeside = 0;
+#ifndef NMPC_SINGLE_PRECISION
+    if (team_wanted(v)) {
+        const unsigned teams = blocks < team::kMaxInstances / kGroupsPerWave ? blocks : team::kMaxInstances / kGroupsPerWave;
+        hipLaunchKernelGGL(k_newton_solve_team, dim3(teams), dim3(team::kWaves * kWave), 0, s, v);
+        if (!v.list) return;
+        teamBeside = 1;
+    }
+#endif
+    if (newton_solve_two_waves(v)) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v, teamBeside);
+    else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v, teamBeside);
 }
 
 #ifdef NMPC_SOLVE_STATS
