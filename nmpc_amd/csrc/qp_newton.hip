@@ -487,6 +487,9 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 }
 
 
+#ifdef NMPC_SOLVE_STATS
+__device__ unsigned long long g_team_stats[16];   // per wave of a team: cycles, cycles waited, looks, sweeps
+#endif
 #ifndef NMPC_SINGLE_PRECISION
 // ------------------------------------------------------------------------
 // Team form of the bottom-up sweep: the four wavefronts of a workgroup, one per
@@ -499,21 +502,26 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 // sweeps, or a small batch) they take those instructions over:
 //
 //   wave 0 (kFactor)   the diagonal block's rows: the chain and the products of
-//                      its own rows (dual_qp.c:835-887)
+//                      its own rows (dual_qp.c:835-887); the last row of the
+//                      sub-diagonal block from the numerator wave 1 prepared
 //   wave 1 (kSub)      the sub-diagonal block's rows (dual_qp.c:889-901), one row
 //                      behind
 //   wave 2 (kProd)     the products of the finished sub-diagonal rows that the
-//                      block above will subtract (dual_qp.c:845-847, 879-883),
-//                      two rows behind
+//                      block above will subtract (dual_qp.c:845-847, 879-883)
 //   wave 3 (kSubst)    the bottom-up substitution (dual_qp.c:1003-1026) and the
 //                      stores of the factor, one block behind
 //
 // Lane i of every wavefront works on the same (instance, column) pair, so a value
-// passes from wave to wave through one LDS word per lane.  The wavefronts run in
-// lock step, thirteen workgroup barriers per block (one per row and one for the
-// hand-over of the last row's products); a row is published by the barrier that
-// follows its write, and wave 0 reaches that barrier a few instructions into its
-// next row, so that it never waits for its own LDS write.
+// passes from wave to wave through one LDS word per lane.  There are no workgroup
+// barriers inside the sweep (a barrier stops the chain for 40 to 130 cycles, twelve
+// times a block): a producer writes its data and then a progress counter, the LDS
+// carries out one wavefront's accesses in order, and a consumer that finds the
+// counter far enough reads the data behind it.  Wave 0 never waits for its own
+// writes; it looks at the others' counters where it needs their results, which
+// are normally long there: the products of the block below (rows 2 .. 11 by wave
+// 2, the three rows the block starts with for row 1 by wave 1 and for row 0 by
+// itself), the numerator of the sub-diagonal block's last row, and wave 3 having
+// taken the rows of the block before last out of the buffer it is about to reuse.
 //
 // Every value is computed by the same operations in the same order as in
 // backward_pass, by whichever wavefront.  What the team does not handle itself
@@ -524,30 +532,131 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 namespace team {
 
 constexpr int kWaves = 4;
-constexpr int kFactor = 0, kSub = 1, kProd = 2, kSubst = 3;
+constexpr int kFactor = 0, kSub = 1, kProd = 2;      // (wave 3: the substitution)
 constexpr int kTri = NX * (NX + 1) / 2;     // (row, column <= row) pairs of a diagonal block
 constexpr int kProducts = kGroupsPerWave * kTri * NX;
 constexpr int kMaxInstances = 4 * 256;      // beyond one team per CU the one-wavefront form has the higher throughput
+// Rows NX-1 .. NX-kUrgent of a block are under way before wave 2 can have delivered
+// the products of the last two rows of the block below.
+constexpr int kUrgent = 3;
+
+typedef int flags4 __attribute__((ext_vector_type(4)));
+
+// (see c_slot)
+constexpr int c_pair_stride(int JJ) { return 2 * kGroupsPerWave * (JJ + 1); }
+constexpr int kSpare = 2 * kWave + (NX / 2) * c_pair_stride(NX - 1);
 
 struct Shared {
     pair_a frow[2][NX][kWave];      // by block parity: row of the diagonal block's factor {lane's entry, RN(1 / pivot)}
     real_t brow[2][NX][kWave];      // row of the sub-diagonal block's factor
-    // Products Ls[l][t] * Ls[l][jj] of the block below, by block parity; the twelve
-    // l of (row jj, column t <= jj) of a group are adjacent (see c_slot).  Lanes
-    // right of the diagonal write theirs into the spare words at the end.
-    __attribute__((aligned(16))) real_t cprod[2][kProducts + kWave + NX];
+    real_t num0[2][kWave];          // numerator of the sub-diagonal block's row 0
+    // Products Ls[l][t] * Ls[l][jj] of the block below, by block parity (see c_slot)
+    __attribute__((aligned(16))) real_t cprod[2][kProducts + kSpare];
     real_t minDiag[kWave];
-    int bail;
+    // Progress counters, one writer each at any time; four to a group so that a
+    // look at them is one LDS read.  Slot i (block N-1-i), row R counts as row_seq(i, R).
+    //   done[0]  wave 1: products of row 1 for the urgent rows made (i + 1)
+    //   done[1]  wave 2: products of a row for every row of the block above made (row_seq)
+    //   done[2]  wave 3: rows of slot i taken out of frow / brow (i + 1)
+    //   done[3]  wave 1: num0 written (i + 1)
+    //   rows[0]  wave 0: row of the diagonal block published (row_seq)
+    //   rows[1]  wave 1: row 11 .. 1 of the sub-diagonal block published (row_seq)
+    //   rows[2]  row 0 of the sub-diagonal block published (i + 1): wave 0, or wave 1 for a stored block
+    //   rows[3]  wave 0: the sweep is given up
+    __attribute__((aligned(16))) int done[4];
+    __attribute__((aligned(16))) int rows[4];
+#ifdef NMPC_SOLVE_STATS
+    long long waited[kWaves], looked[kWaves];     // per wavefront: cycles and looks spent in waits
+#endif
 };
+#ifdef NMPC_SOLVE_STATS
+struct WaitClock {
+    Shared& sh;
+    long long t0;
+    int n = 0;
+    __device__ explicit WaitClock(Shared& s) : sh(s), t0(clock64()) {}
+    __device__ ~WaitClock() {
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            sh.waited[threadIdx.x >> 6] += clock64() - t0;
+            sh.looked[threadIdx.x >> 6] += n;
+        }
+    }
+};
+#define NMPC_WAIT_CLOCK(sh) WaitClock wait_clock_(sh)
+#define NMPC_WAIT_LOOK() (++wait_clock_.n)
+#else
+#define NMPC_WAIT_CLOCK(sh)
+#define NMPC_WAIT_LOOK()
+#endif
 
-// First of the twelve products of (row JJ, column t <= JJ) of group g.
+NMPC_DEV constexpr int row_seq(int i, int R) { return i * 16 + (NX - R); }
+
+// Counters and what they guard are read and written as LDS accesses proper (a
+// volatile access through a generic pointer would go the flat way and wait for
+// every load in flight).
+#define NMPC_LDS __attribute__((address_space(3)))
+NMPC_DEV flags4 peek(const int* group) { return *(const volatile NMPC_LDS flags4*)group; }
+NMPC_DEV real_t peek_value(const real_t* at) { return *(const volatile NMPC_LDS real_t*)at; }
+// After the data it stands for (the compiler keeps the order, the LDS does the rest).
+NMPC_DEV void post(int* counter, int value) {
+    asm volatile("" ::: "memory");
+    *(volatile NMPC_LDS int*)counter = value;
+    asm volatile("" ::: "memory");
+}
+// Every wait looks at rows[3] as well and ends when the sweep is given up, and no
+// wait goes on for ever: after kPatience looks (a tenth of a second, where a
+// counter normally is there at the first look) the sweep is given up from here.
+constexpr int kPatience = 1 << 21;
+NMPC_DEV bool out_of_patience(Shared& sh, int& looks) {
+    if (++looks < kPatience) return false;
+    post(&sh.rows[3], 2);
+    return true;
+}
+// Until rows[A] >= a and rows[B] >= b; false when the sweep is given up.
+template <int A, int B>
+NMPC_DEV bool await_rows(Shared& sh, int a, int b) {
+#ifdef NMPC_TEAM_SOLO
+    return true;
+#endif
+    NMPC_WAIT_CLOCK(sh);
+    for (int looks = 0;;) {
+        NMPC_WAIT_LOOK();
+        const flags4 f = peek(sh.rows);
+        if (f[3] != 0) return false;
+        if (f[A] >= a && f[B] >= b) return true;
+        if (out_of_patience(sh, looks)) return false;
+    }
+}
+// Until done[A] >= a and done[B] >= b.
+template <int A, int B>
+NMPC_DEV bool await_done(Shared& sh, int a, int b) {
+#ifdef NMPC_TEAM_SOLO
+    return true;
+#endif
+    NMPC_WAIT_CLOCK(sh);
+    for (int looks = 0;;) {
+        NMPC_WAIT_LOOK();
+        const flags4 f = peek(sh.done);
+        if (f[A] >= a && f[B] >= b) return true;
+        if (peek(sh.rows)[3] != 0 || out_of_patience(sh, looks)) return false;
+    }
+}
+NMPC_DEV bool await_taken(Shared& sh, int i) {       // frow / brow of slot i - 2 are free again
+    return i < 2 || await_done<2, 2>(sh, i - 1, 0);
+}
+
+// Products of the block below for row JJ of the block above: only the columns
+// t <= JJ of each group use them, 4 (JJ + 1) lanes; their pairs (l, l + 1) lie lane
+// after lane, sixteen bytes each, so that neither the reads nor the writes of a
+// wavefront collide in the LDS banks.  In doubles: first pair of (row JJ, lane).
 template <int JJ>
 NMPC_DEV int c_slot(int g, int t) {
-    constexpr int T = JJ * (JJ + 1) / 2;
-    return (T * kGroupsPerWave + g * (JJ + 1) + t) * NX;
+    constexpr int T = JJ * (JJ + 1) / 2;                    // (row, column) pairs of the rows before
+    return T * kGroupsPerWave * NX + 2 * (g * (JJ + 1) + t);
 }
 // Per lane and row: where the lane reads its twelve products (any valid place
-// right of the diagonal, where nothing uses them) and where it writes them.
+// right of the diagonal, where nothing uses them) and where it writes them
+// (right of the diagonal: into the spare words behind the products).
 struct Slots { int at[NX]; };
 template <int... JJ>
 NMPC_DEV Slots read_slots(int g, int t, std::integer_sequence<int, JJ...>) {
@@ -555,19 +664,15 @@ NMPC_DEV Slots read_slots(int g, int t, std::integer_sequence<int, JJ...>) {
 }
 template <int... JJ>
 NMPC_DEV Slots write_slots(int g, int t, int lane, std::integer_sequence<int, JJ...>) {
-    return Slots{{(t <= JJ ? c_slot<JJ>(g, t) : kProducts + lane)...}};
+    return Slots{{(t <= JJ ? c_slot<JJ>(g, t) : kProducts + 2 * lane)...}};
 }
 
-// A row is published to the other wavefronts by the barrier behind its write.
-NMPC_DEV void team_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-NMPC_DEV void read_products(const real_t* at, real_t (&cc)[NX]) {
-    const pair_a* p = (const pair_a*)at;
+template <int JJ>
+NMPC_DEV void read_products(const real_t* cbuf, const Slots& rd, real_t (&cc)[NX]) {
+    const real_t* at = cbuf + rd.at[JJ];
 #pragma unroll
     for (int l = 0; l < NX / 2; l++) {
-        const pair_a v = p[l];
+        const pair_a v = *(const pair_a*)(at + l * c_pair_stride(JJ));
         cc[2 * l] = v.x;
         cc[2 * l + 1] = v.y;
     }
@@ -578,12 +683,13 @@ NMPC_DEV void read_products(const real_t* at, real_t (&cc)[NX]) {
 // its term R.
 template <int JJ>
 NMPC_DEV void row_product(real_t* cbuf, const Slots& w, real_t ls, int R) {
-    cbuf[w.at[JJ] + R] = ls * row_bcast<JJ>(ls);
+    cbuf[w.at[JJ] + (R / 2) * c_pair_stride(JJ) + (R & 1)] = ls * row_bcast<JJ>(ls);
 }
 template <int FIRST, int... J>
 NMPC_DEV void row_products(real_t* cbuf, const Slots& w, real_t ls, int R, std::integer_sequence<int, J...>) {
     (row_product<FIRST + J>(cbuf, w, ls, R), ...);
 }
+using SeqUrgent = std::make_integer_sequence<int, kUrgent>;
 
 // ---- wave 0 ----------------------------------------------------------------
 // Item I of the products of row JJ with the rows below it: L[l][t] * L[l][JJ], l = JJ + 2 + I.
@@ -612,114 +718,148 @@ NMPC_DEV void factor_chain(real_t& sum, const real_t (&pa)[NX], real_t (&qa)[NX]
     (factor_chain_step<JJ, S>(sum, pa, qa, cc, L), ...);
 }
 
-// Row JJ of the diagonal block of block row k: on entry cc holds the products of
-// the block below for this row, pa this row's products with the rows below it;
-// on exit they hold those of row JJ - 1.
+struct FactorState {
+    bool watch;         // the lane's group factorises this block for good (a failure counts)
+    bool bad;           // a failed pivot, or a root the reciprocal is not good for, in this block
+    bool bail;
+};
+
+// Row JJ of the diagonal block of slot i: on entry cc holds the products of the
+// block below for this row, pa this row's products with the rows below it; on
+// exit they hold those of row JJ - 1.  prevSeq: what done[1] shows once every
+// product of the block below is made.
 template <int JJ>
-NMPC_DEV void factor_row(Shared& sh, int par, const real_t* cbuf, const Slots& rd, const real_t (&Hd)[NX],
-                         real_t (&L)[NX], real_t (&pa)[NX], real_t (&cc)[NX], int t, int lane,
-                         int& failCol, uint32_t& ones) {
+NMPC_DEV void factor_row(Shared& sh, int par, int i, int prevSeq, const real_t* cbuf, real_t* cout,
+                         const Slots& rd, const Slots& wr, const real_t (&Hd)[NX], real_t (&L)[NX],
+                         real_t (&pa)[NX], real_t (&cc)[NX], int t, int lane, FactorState& fs) {
     constexpr int nA = JJ + 2 < NX ? NX - 2 - JJ : 0;
     real_t sum = Hd[JJ];
     if constexpr (JJ + 1 < NX) {
         sum -= L[JJ + 1] * row_bcast<JJ>(L[JJ + 1]);        // the row just finished
         NMPC_PIN(sum);
-        team_barrier();                                     // ... which this publishes
+    }
+    // the numerator of the sub-diagonal block's last row: asked for now, looked at below
+    flags4 seen{0, 0, 0, 0};
+    real_t num = 0.;
+    if constexpr (JJ == 0) {
+        seen = peek(sh.done);
+        num = peek_value(&sh.num0[par][lane]);
     }
     real_t cn[NX];
-    if constexpr (JJ > 0) read_products(cbuf + rd.at[JJ - 1], cn);
+    if constexpr (JJ > 0) {
+        // the first row past the urgent ones needs every product of the block below
+        if constexpr (JJ - 1 == NX - 1 - kUrgent) {
+            if (prevSeq > 0 && !fs.bail && !await_done<1, 1>(sh, prevSeq, 0)) fs.bail = true;
+        }
+        read_products<JJ - 1>(cbuf, rd, cn);
+    }
     real_t qa[NX];
     factor_chain<JJ>(sum, pa, qa, cc, L, std::make_integer_sequence<int, nA + NX>{});
     const real_t piv = row_bcast<JJ>(sum);
-    if (failCol < 0 && piv < 1.e2 * kEqTol) failCol = JJ;
     const Pivot pv = root_and_reciprocal(piv);
     const real_t ld = divide<true>(sum, pv);
-    const uint32_t lo = (uint32_t)__double_as_longlong(pv.d);
-    ones = lo > ones ? lo : ones;
+    // a failed pivot (dual_qp.c:859-861) or a root the reciprocal is not good for
+    fs.bad = fs.bad || (fs.watch && (piv < 1.e2 * kEqTol || (uint32_t)__double_as_longlong(pv.d) == 0xffffffffu));
+    if constexpr (JJ == 0) {
+        // given up before the block's last row is published, so that wave 3 stores nothing of it
+        if (__any(fs.bad) && !fs.bail) {
+            post(&sh.rows[3], 1);
+            fs.bail = true;
+        }
+    }
     L[JJ] = (t == JJ) ? pv.d : ld;
     pair_a out;
     out.x = L[JJ];
     out.y = pv.y;
     sh.frow[par][JJ][lane] = out;
+    post(&sh.rows[0], row_seq(i, JJ));
     if constexpr (JJ > 0) {
 #pragma unroll
         for (int l = JJ + 1; l < NX; l++) pa[l] = qa[l];
 #pragma unroll
         for (int l = 0; l < NX; l++) cc[l] = cn[l];
+    } else {
+        // row 0 of the sub-diagonal block, and what the block above needs of it at once
+        NMPC_WAIT_CLOCK(sh);
+#ifdef NMPC_TEAM_SOLO
+        seen[3] = i + 1;
+#endif
+        for (int looks = 0; seen[3] < i + 1 && !fs.bail;) {
+            NMPC_WAIT_LOOK();
+            seen = peek(sh.done);
+            num = peek_value(&sh.num0[par][lane]);
+            if (peek(sh.rows)[3] != 0 || out_of_patience(sh, looks)) fs.bail = true;
+        }
+        const real_t ls0 = divide<true>(num, pv);
+        sh.brow[par][0][lane] = ls0;
+        post(&sh.rows[2], i + 1);
+        row_products<NX - kUrgent>(cout, wr, ls0, 0, SeqUrgent{});
     }
 }
 
 template <int... R>
-NMPC_DEV void factor_rows(Shared& sh, int par, const real_t* cbuf, const Slots& rd, const real_t (&Hd)[NX],
-                          real_t (&L)[NX], int t, int lane, int& failCol, uint32_t& ones,
-                          std::integer_sequence<int, R...>) {
+NMPC_DEV void factor_rows(Shared& sh, int par, int i, int prevSeq, const real_t* cbuf, real_t* cout,
+                          const Slots& rd, const Slots& wr, const real_t (&Hd)[NX], real_t (&L)[NX],
+                          int t, int lane, FactorState& fs, std::integer_sequence<int, R...>) {
     real_t pa[NX], cc[NX];
-    read_products(cbuf + rd.at[NX - 1], cc);
-    (factor_row<NX - 1 - R>(sh, par, cbuf, rd, Hd, L, pa, cc, t, lane, failCol, ones), ...);
+    read_products<NX - 1>(cbuf, rd, cc);
+    (factor_row<NX - 1 - R>(sh, par, i, prevSeq, cbuf, cout, rd, wr, Hd, L, pa, cc, t, lane, fs), ...);
 }
 
 // ---- wave 1 ----------------------------------------------------------------
-// Row R of the sub-diagonal block once row R of the diagonal block is published:
-// its quotient, then the chain of row R - 1 up to the division.  sub holds the
-// numerator of row R on entry and that of row R - 1 on exit.  The last row's
-// products for the two rows the block above starts with are made here as well:
-// wave 0 waits for them.
+// Row R >= 1 of the sub-diagonal block once row R of the diagonal block is
+// published: its quotient, then the chain of row R - 1 up to the division.  sub
+// holds the numerator of row R on entry and that of row R - 1 on exit.  Row 0's
+// numerator goes to wave 0, which has the pivot first; row 1's products for the
+// rows the block above starts with are made here, wave 2 would be late with them.
 template <int R>
-NMPC_DEV void sub_row(Shared& sh, int par, real_t* cbuf, const Slots& wr, bool fromHess, const real_t (&Hs)[NX],
+NMPC_DEV bool sub_row(Shared& sh, int par, int i, real_t* cbuf, const Slots& wr, const real_t (&Hs)[NX],
                       real_t (&L)[NX], real_t (&Ls)[NX], real_t& sub, int lane) {
     NMPC_PIN(sub);                          // the numerator is ready before the pivot is
-    team_barrier();                         // row R of the diagonal block is there
+    if (!await_rows<0, 0>(sh, row_seq(i, R), 0)) return false;
     const pair_a in = sh.frow[par][R][lane];
     L[R] = in.x;
     const Pivot pv{row_bcast<R>(in.x), in.y};
-    const real_t ls = divide<true>(sub, pv);
-    Ls[R] = fromHess ? ls : Ls[R];          // (else Ls holds the stored factor)
+    Ls[R] = divide<true>(sub, pv);
     sh.brow[par][R][lane] = Ls[R];
-    if constexpr (R > 0) {
-        sub = Hs[R - 1];
+    post(&sh.rows[1], row_seq(i, R));
+    sub = Hs[R - 1];
 #pragma unroll
-        for (int l = R; l < NX; l++) sub -= Ls[l] * row_bcast<R - 1>(L[l]);
-    } else {
-        row_products<NX - 2>(cbuf, wr, Ls[0], 0, std::make_integer_sequence<int, 2>{});
+    for (int l = R; l < NX; l++) sub -= Ls[l] * row_bcast<R - 1>(L[l]);
+    if constexpr (R == 1) {
+        sh.num0[par][lane] = sub;
+        post(&sh.done[3], i + 1);
+        row_products<NX - kUrgent>(cbuf, wr, Ls[1], 1, SeqUrgent{});
+        post(&sh.done[0], i + 1);
     }
+    return true;
 }
 
 template <int... R>
-NMPC_DEV void sub_rows(Shared& sh, int par, real_t* cbuf, const Slots& wr, bool fromHess, const real_t (&Hs)[NX],
+NMPC_DEV bool sub_rows(Shared& sh, int par, int i, real_t* cbuf, const Slots& wr, const real_t (&Hs)[NX],
                        real_t (&L)[NX], real_t (&Ls)[NX], int lane, std::integer_sequence<int, R...>) {
     real_t sub = Hs[NX - 1];
-    (sub_row<NX - 1 - R>(sh, par, cbuf, wr, fromHess, Hs, L, Ls, sub, lane), ...);
+    return (sub_row<NX - 1 - R>(sh, par, i, cbuf, wr, Hs, L, Ls, sub, lane) && ...);
 }
 
 // ---- wave 2 ----------------------------------------------------------------
-// Barrier b = 1 .. 13 of a slot.  Row R of block k's sub-diagonal block is written
-// between the barriers 13 - R and 14 - R, so it is read behind barrier 14 - R: rows
-// 11 .. 1 behind the barriers 3 .. 13 of their own slot, row 0 behind barrier 1 of
-// the next (its products for the first two rows of the block above are wave 1's).
-template <int BAR>
-NMPC_DEV void prod_step(Shared& sh, int parK, int parM, const Slots& wr, bool haveK, bool haveM, int lane) {
-    team_barrier();
-    if constexpr (BAR == 1) {
-        if (haveM) row_products<0>(sh.cprod[parM], wr, sh.brow[parM][0][lane], 0, std::make_integer_sequence<int, NX - 2>{});
-    } else if constexpr (BAR >= 3) {
-        constexpr int R = 14 - BAR;
-        if (haveK) row_products<0>(sh.cprod[parK], wr, sh.brow[parK][R][lane], R, std::make_integer_sequence<int, NX>{});
-    }
+template <int R>
+NMPC_DEV bool prod_row(Shared& sh, int par, int i, const Slots& wr, int lane) {
+    if (R > 0 ? !await_rows<1, 1>(sh, row_seq(i, R), 0) : !await_rows<2, 2>(sh, i + 1, 0)) return false;
+    row_products<0>(sh.cprod[par], wr, sh.brow[par][R][lane], R, Seq12{});
+    post(&sh.done[1], row_seq(i, R));
+    return true;
 }
-template <int... BAR>
-NMPC_DEV void prod_steps(Shared& sh, int parK, int parM, const Slots& wr, bool haveK, bool haveM, int lane,
-                         std::integer_sequence<int, BAR...>) {
-    (prod_step<1 + BAR>(sh, parK, parM, wr, haveK, haveM, lane), ...);
+template <int... R>
+NMPC_DEV bool prod_rows(Shared& sh, int par, int i, const Slots& wr, int lane, std::integer_sequence<int, R...>) {
+    return (prod_row<NX - 1 - R>(sh, par, i, wr, lane) && ...);
 }
 
 // ---- wave 3 ----------------------------------------------------------------
-// Step R of a slot: row R of the substitution of block m and the stores of row R
-// of its factor.
 template <bool FAST, int R>
 NMPC_DEV void subst_row(bool storeM, bool storeSub, real_t* cholRow, real_t (&xk)[NX], real_t& mine,
                         const real_t (&L)[NX], const real_t (&Ls)[NX], const real_t (&pn)[NX], real_t gm,
                         const Pivot& dd, int t) {
-    team_barrier();
     backsolve_row<FAST, R>(xk, mine, L, pn, gm, dd, t);
     if (storeM) {
         if (R >= t) cholRow[kCholDiagRow[R] + t] = L[R];
@@ -734,14 +874,9 @@ NMPC_DEV void subst_rows(bool storeM, bool storeSub, real_t* cholRow, real_t (&x
     (subst_row<FAST, NX - 1 - R>(storeM, storeSub, cholRow, xk, mine, L, Ls, pn, gm, dd, t), ...);
 }
 
-NMPC_DEV void idle_slot() {
-#pragma unroll
-    for (int r = 0; r < NX; r++) team_barrier();
-}
-
-// The sweep.  Slot i = 0 .. N: waves 0 to 2 work on block k = N - 1 - i (none in
-// the last slot), wave 3 on block m = k + 1 (none in the first).  Returns true
-// when the sweep was given up (`bail`); minDiag as backward_pass leaves it.
+// The sweep, slot i = 0 .. N-1 for block k = N-1-i, every wavefront at its own
+// pace.  Returns true when the sweep was given up (`bail`); minDiag as
+// backward_pass leaves it.
 NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bool active, int role,
                     int lane, real_t& minDiag) {
     const int N = v.N;
@@ -753,21 +888,25 @@ NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bo
     {
         real_t* c0 = sh.cprod[N & 1];
         for (int i = threadIdx.x; i < kProducts; i += kWaves * kWave) c0[i] = 0.;
-        if (threadIdx.x == 0) sh.bail = 0;
+        if (threadIdx.x < 4) { sh.done[threadIdx.x] = 0; sh.rows[threadIdx.x] = 0; }
+#ifdef NMPC_SOLVE_STATS
+        if (threadIdx.x < kWaves) { sh.waited[threadIdx.x] = 0; sh.looked[threadIdx.x] = 0; }
+#endif
     }
     __syncthreads();
+#ifdef NMPC_SOLVE_STATS
+    const long long sweep0 = clock64();
+#endif
 
-    const Slots slots = role == kFactor ? read_slots(g, tc, Seq12{}) : write_slots(g, t, lane, Seq12{});
-    real_t L[NX], Ls[NX];           // wave 0: L; wave 1: both; wave 3: those of block m
-    real_t nA[NX], ng = 0.;         // the column fetched for the next slot (Hessian or stored factor)
-    real_t xk[NX], pn[NX];          // wave 3
-#pragma unroll
-    for (int l = 0; l < NX; l++) { L[l] = 0.; Ls[l] = 0.; nA[l] = 0.; xk[l] = 0.; pn[l] = 0.; }
-
+    const Slots rd = read_slots(g, tc, Seq12{});
+    const Slots wr = write_slots(g, t, lane, Seq12{});
     // Column tc of block row kk: from the Newton Hessian when the block is
     // factorised, from the stored factor otherwise (one load per value, its place
     // chosen between the two layouts).  Wave 0 takes the diagonal block, wave 1
     // the sub-diagonal block.
+    real_t nA[NX];
+#pragma unroll
+    for (int l = 0; l < NX; l++) nA[l] = 0.;
     auto fetch = [&](int kk) {
         if (kk < 0 || !active) return;
         const bool fromH = kk <= maxStart;
@@ -780,99 +919,132 @@ NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bo
             for (int l = 0; l < NX; l++) nA[l] = row[fromH ? l * 2 * NX : NX * l];
         }
     };
-    if (role == kSubst) { if (active) ng = I.grad[(N - 1) * NX + tc]; }
-    else if (role != kProd) fetch(N - 1);
 
     bool bail = false;
-    for (int i = 0; i <= N && !bail; ++i) {
-        const int k = N - 1 - i, m = k + 1;
-        const bool haveK = k >= 0, haveM = m <= N - 1;
-        const bool fromHess = haveK && k <= maxStart;
-        const int parK = k & 1, parM = m & 1;
-        if (role == kFactor) {
-            real_t A[NX];
-#pragma unroll
-            for (int l = 0; l < NX; l++) A[l] = nA[l];
-            fetch(k - 1);
-            team_barrier();         // the products of the block below are complete
-            if (fromHess) {
-                int failCol = -1;
-                uint32_t ones = 0;
-                factor_rows(sh, parK, sh.cprod[parM], slots, A, L, t, lane, failCol, ones, Seq12{});
-                const bool failed = active && k <= start && failCol >= 0;
-                bool giveUp = __any(failed || (active && ones == 0xffffffffu));
-#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: give up half-way through every sweep
-                giveUp = giveUp || k == N / 2;
+#ifdef NMPC_TEAM_SOLO       // timing experiment: wave 0 alone, nothing it waits for ever comes
+    if (role != kFactor) bail = true;
 #endif
-                if (giveUp && lane == 0) sh.bail = 1;
-                team_barrier();     // row 0
-            } else {
-                if (haveK) {
+    if (role == kFactor) {
+        real_t L[NX];
 #pragma unroll
-                    for (int l = 0; l < NX; l++) {
-                        pair_a out;
-                        out.x = A[l];
-                        out.y = 0.;
-                        sh.frow[parK][l][lane] = out;
-                    }
-                }
-                idle_slot();
-            }
-        } else if (role == kSub) {
+        for (int l = 0; l < NX; l++) L[l] = 0.;
+        fetch(N - 1);
+        for (int i = 0; i < N && !bail; ++i) {
+            const int k = N - 1 - i, par = k & 1;
             real_t A[NX];
 #pragma unroll
             for (int l = 0; l < NX; l++) A[l] = nA[l];
             fetch(k - 1);
-            team_barrier();
-            if (haveK) {
-                if (!fromHess) {
-#pragma unroll
-                    for (int l = 0; l < NX; l++) Ls[l] = A[l];
+            if (!await_taken(sh, i)) { bail = true; break; }
+            if (k <= maxStart) {
+                // products of the block below: all of them when it was a stored block,
+                // else rows 2 .. 11 from wave 2, row 1's urgent ones from wave 1 (row 0's are this wave's own)
+                int prevSeq = 0;
+                if (i > 0) {
+                    const bool belowFactorised = k + 1 <= maxStart;
+                    prevSeq = row_seq(i - 1, 0);
+                    const int needProd = belowFactorised ? row_seq(i - 1, 2) : prevSeq;
+                    const int needUrgent = belowFactorised ? i : 0;
+                    if (!await_done<1, 0>(sh, needProd, needUrgent)) { bail = true; break; }
                 }
-                sub_rows(sh, parK, sh.cprod[parK], slots, fromHess, A, L, Ls, lane, Seq12{});
+#ifdef NMPC_TEAM_SOLO
+                FactorState fs{false, false, false};
+#else
+                FactorState fs{active && k <= start, false, false};
+#endif
+                factor_rows(sh, par, i, prevSeq, sh.cprod[par ^ 1], sh.cprod[par], rd, wr, A, L, t, lane, fs, Seq12{});
+                bail = fs.bail;
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: give up half-way through every sweep
+                if (k == N / 2 && !bail) { post(&sh.rows[3], 1); bail = true; }
+#endif
             } else {
-                idle_slot();
-            }
-        } else if (role == kProd) {
-            prod_steps(sh, parK, parM, slots, haveK, haveM, lane, std::make_integer_sequence<int, NX + 1>{});
-        } else {
-            const real_t gm = ng;
-            if (haveK && active) ng = I.grad[k * NX + tc];
-            team_barrier();
-            if (haveM) {
-                // block m is complete: the lane's column of both blocks, its own pivot
 #pragma unroll
                 for (int l = 0; l < NX; l++) {
-                    L[l] = sh.frow[parM][l][lane].x;
-                    Ls[l] = sh.brow[parM][l][lane];
+                    pair_a out;
+                    out.x = A[l];
+                    out.y = 0.;
+                    sh.frow[par][l][lane] = out;
                 }
-                const pair_a own = sh.frow[parM][tc][lane];
-                const bool mFromHess = m <= maxStart;
-                Pivot dd;
-                dd.d = active ? own.x : 1.;
-                dd.y = mFromHess ? own.y : 1.0 / dd.d;
-                if (col && minDiag > dd.d) minDiag = dd.d;
-                const bool storeM = active && col && m <= start;
-                real_t* cholRow = I.chol + (size_t)m * kCholRow;
-                real_t mine = 0.;
-                if (!mFromHess && __any(plain_division_needed(dd.d)))
-                    subst_rows<false>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
-                else
-                    subst_rows<true>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
-                // into scratch: the step itself is only written once the factor is known to be good
-                if (active && col) I.tmp[m * NX + t] = mine;
-#pragma unroll
-                for (int j = 0; j < NX; j++) pn[j] = Ls[j] * xk[j];
-            } else {
-                idle_slot();
+                post(&sh.rows[0], row_seq(i, 0));
             }
         }
-        bail = sh.bail != 0;        // read before this wavefront's next barrier, written before the last one
+    } else if (role == kSub) {
+        real_t L[NX], Ls[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) { L[l] = 0.; Ls[l] = 0.; }
+        fetch(N - 1);
+        for (int i = 0; i < N && !bail; ++i) {
+            const int k = N - 1 - i, par = k & 1;
+            real_t A[NX];
+#pragma unroll
+            for (int l = 0; l < NX; l++) A[l] = nA[l];
+            fetch(k - 1);
+            if (k <= maxStart) {
+                bail = !sub_rows(sh, par, i, sh.cprod[par], wr, A, L, Ls, lane, std::make_integer_sequence<int, NX - 1>{});
+            } else {
+                if (!await_taken(sh, i)) { bail = true; break; }
+#pragma unroll
+                for (int l = 0; l < NX; l++) sh.brow[par][l][lane] = A[l];
+                post(&sh.rows[1], row_seq(i, 1));
+                post(&sh.rows[2], i + 1);
+            }
+        }
+    } else if (role == kProd) {
+        // only the block right below a factorised one is asked for its products
+        for (int i = 0; i < N - 1 && !bail; ++i) {
+            const int k = N - 1 - i;
+            if (k - 1 <= maxStart) bail = !prod_rows(sh, k & 1, i, wr, lane, Seq12{});
+        }
+    } else {
+        real_t L[NX], Ls[NX], xk[NX], pn[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) { xk[l] = 0.; pn[l] = 0.; }
+        real_t ng = active ? I.grad[(N - 1) * NX + tc] : 0.;
+        for (int i = 0; i < N && !bail; ++i) {
+            const int m = N - 1 - i, par = m & 1;
+            const real_t gm = ng;
+            if (m > 0 && active) ng = I.grad[(m - 1) * NX + tc];
+            if (!await_rows<0, 2>(sh, row_seq(i, 0), i + 1)) { bail = true; break; }
+            // block m is complete: the lane's column of both blocks, its own pivot
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                L[l] = sh.frow[par][l][lane].x;
+                Ls[l] = sh.brow[par][l][lane];
+            }
+            const pair_a own = sh.frow[par][tc][lane];
+            NMPC_PIN(L[0]);
+            post(&sh.done[2], i + 1);
+            const bool mFromHess = m <= maxStart;
+            Pivot dd;
+            dd.d = active ? own.x : 1.;
+            dd.y = mFromHess ? own.y : 1.0 / dd.d;
+            if (col && minDiag > dd.d) minDiag = dd.d;
+            const bool storeM = active && col && m <= start;
+            real_t* cholRow = I.chol + (size_t)m * kCholRow;
+            real_t mine = 0.;
+            if (!mFromHess && __any(plain_division_needed(dd.d)))
+                subst_rows<false>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
+            else
+                subst_rows<true>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
+            // into scratch: the step itself is only written once the factor is known to be good
+            if (active && col) I.tmp[m * NX + t] = mine;
+#pragma unroll
+            for (int j = 0; j < NX; j++) pn[j] = Ls[j] * xk[j];
+        }
+        sh.minDiag[lane] = minDiag;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the factor and the scratch are stored
     }
-    if (role == kSubst) sh.minDiag[lane] = minDiag;
-    __syncthreads();                // wave 3's stores of the factor and of the scratch are done
+#ifdef NMPC_SOLVE_STATS
+    if (lane == 0) {
+        atomicAdd(&g_team_stats[role * 4 + 0], (unsigned long long)(clock64() - sweep0));
+        atomicAdd(&g_team_stats[role * 4 + 1], (unsigned long long)sh.waited[role]);
+        atomicAdd(&g_team_stats[role * 4 + 2], (unsigned long long)sh.looked[role]);
+        atomicAdd(&g_team_stats[role * 4 + 3], 1ull);
+    }
+#endif
+    __syncthreads();
     if (role == kFactor) minDiag = sh.minDiag[lane];
-    return bail;
+    return sh.rows[3] != 0;
 }
 
 }  // namespace team
@@ -1181,6 +1353,15 @@ void launch_newton_solve(const BatchView& v, hipStream_t s) {
 }
 
 #ifdef NMPC_SOLVE_STATS
+extern "C" int nmpc_debug_team_stats(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_team_stats), sizeof(unsigned long long) * 16) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long zero[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_team_stats), zero, sizeof zero) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int nmpc_debug_solve_stats(unsigned long long* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solve_stats), sizeof(unsigned long long) * 16) != hipSuccess)
         return -1;

@@ -21,8 +21,15 @@ for rep in range(3):
     bt.reset(); bt.initialise_horizon(); bt.set_wind_velocity(d["wind"]); bt.set_reference(d["refs"][:, :N + 1])
     torch.cuda.synchronize()
     lib.nmpc_debug_solve_stats(out, 1)
+    lib.nmpc_debug_team_stats(out, 1)
     bt.solve(d["meas"][:, 0]); bt.get_controls()
     torch.cuda.synchronize()
+    lib.nmpc_debug_team_stats(out, 1)
+    for role, name in enumerate(("factor", "sub", "products", "substitution")):
+        n = out[role * 4 + 3]
+        if n:
+            print("team wave %d %-12s sweeps %5d  cycles %9.0f  of them waiting %9.0f  looks %8.0f"
+                  % (role, name, n, out[role * 4] / n, out[role * 4 + 1] / n, out[role * 4 + 2] / n))
     lib.nmpc_debug_solve_stats(out, 1)
     for name, o in (("first iteration + long parts", 0), ("short parts", 8)):
         n = out[o]
