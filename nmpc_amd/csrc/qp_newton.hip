@@ -492,79 +492,40 @@ __device__ unsigned long long g_team_stats[16];   // per wave of a team: cycles,
 #endif
 #ifndef NMPC_SINGLE_PRECISION
 // ------------------------------------------------------------------------
-// Team form of the bottom-up sweep: the four wavefronts of a workgroup, one per
-// SIMD of a CU, work on the same four instances.  A factorised block is a chain
-// of some 420 dependent operations (per row of the diagonal block: up to 23
-// ordered subtractions, the pivot's root and reciprocal, a quotient) inside about
-// 1 800 instructions, and a wavefront that is alone on its SIMD issues one
-// instruction every five cycles: the instructions that are not the chain cost
-// more than the chain does.  Where SIMDs are idle anyway (few instances with long
-// sweeps, or a small batch) they take those instructions over:
+// Team form of the bottom-up sweep: two wavefronts on two SIMDs of a CU work on
+// the same four instances.  Wave 0 factorises block after block exactly as
+// backward_pass does (the same column routine) and hands the finished block row
+// over through LDS; wave 1, one block behind, does the bottom-up substitution
+// (dual_qp.c:1003-1026), which needs nothing but the finished rows, and stores
+// the factor.  That takes the substitution's 330 instructions and the 24 stores
+// out of the 1 800 a lone wavefront issues per factorised block, one every five
+// or six cycles; where SIMDs are idle anyway (few instances with long sweeps, a
+// small batch) the second wavefront is free.
 //
-//   wave 0 (kFactor)   the diagonal block's rows: the chain and the products of
-//                      its own rows (dual_qp.c:835-887); the last row of the
-//                      sub-diagonal block from the numerator wave 1 prepared
-//   wave 1 (kSub)      the sub-diagonal block's rows (dual_qp.c:889-901), one row
-//                      behind
-//   wave 2 (kProd)     the products of the finished sub-diagonal rows that the
-//                      block above will subtract (dual_qp.c:845-847, 879-883)
-//   wave 3 (kSubst)    the bottom-up substitution (dual_qp.c:1003-1026) and the
-//                      stores of the factor, one block behind
+// Lane i of both wavefronts works on the same (instance, column) pair, so a value
+// passes through one LDS word per lane.  No workgroup barrier inside the sweep (one
+// stops the wavefront for 40 to 130 cycles, tools/micro_barrier.hip): wave 0 writes
+// a block row and then a counter, the LDS carries out a wavefront's accesses in
+// order, and wave 1, finding the counter far enough, reads the rows behind it and
+// says so in a counter of its own, which wave 0 looks at before it reuses the
+// buffer (two block rows, by block parity).
 //
-// Lane i of every wavefront works on the same (instance, column) pair, so a value
-// passes from wave to wave through one LDS word per lane.  There are no workgroup
-// barriers inside the sweep (a barrier stops the chain for 40 to 130 cycles, twelve
-// times a block): a producer writes its data and then a progress counter, the LDS
-// carries out one wavefront's accesses in order, and a consumer that finds the
-// counter far enough reads the data behind it.  Wave 0 never waits for its own
-// writes; it looks at the others' counters where it needs their results, which
-// are normally long there: the products of the block below (rows 2 .. 11 by wave
-// 2, the three rows the block starts with for row 1 by wave 1 and for row 0 by
-// itself), the numerator of the sub-diagonal block's last row, and wave 3 having
-// taken the rows of the block before last out of the buffer it is about to reuse.
-//
-// Every value is computed by the same operations in the same order as in
-// backward_pass, by whichever wavefront.  What the team does not handle itself
-// -- a failed pivot, a pivot root whose significand is all ones -- makes it stop
-// (`bail`); the caller then repeats the sweep with backward_pass, which is
-// possible because everything the team has stored by then is what that sweep
-// stores again.
+// What the team does not handle itself -- a failed pivot, a pivot root whose
+// significand is all ones -- makes it stop (`bail`) before the block is handed
+// over; the caller then repeats the sweep with backward_pass, which is possible
+// because everything the team has stored by then is what that sweep stores again.
 namespace team {
 
-constexpr int kWaves = 4;
-constexpr int kFactor = 0, kSub = 1, kProd = 2;      // (wave 3: the substitution)
-constexpr int kTri = NX * (NX + 1) / 2;     // (row, column <= row) pairs of a diagonal block
-constexpr int kProducts = kGroupsPerWave * kTri * NX;
-constexpr int kMaxInstances = 4 * 256;      // beyond one team per CU the one-wavefront form has the higher throughput
-// Rows NX-1 .. NX-kUrgent of a block are under way before wave 2 can have delivered
-// the products of the last two rows of the block below.
-constexpr int kUrgent = 3;
+constexpr int kWaves = 2;
+constexpr int kMaxInstances = 4 * 512;      // two teams per CU; beyond, the one-wavefront form has the higher throughput
 
 typedef int flags4 __attribute__((ext_vector_type(4)));
 
-// (see c_slot)
-constexpr int c_pair_stride(int JJ) { return 2 * kGroupsPerWave * (JJ + 1); }
-constexpr int kSpare = 2 * kWave + (NX / 2) * c_pair_stride(NX - 1);
-
 struct Shared {
-    pair_a frow[2][NX][kWave];      // by block parity: row of the diagonal block's factor {lane's entry, RN(1 / pivot)}
-    real_t brow[2][NX][kWave];      // row of the sub-diagonal block's factor
-    real_t num0[2][kWave];          // numerator of the sub-diagonal block's row 0
-    // Products Ls[l][t] * Ls[l][jj] of the block below, by block parity (see c_slot)
-    __attribute__((aligned(16))) real_t cprod[2][kProducts + kSpare];
+    pair_a row[2][NX][kWave];       // by block parity: row l of the block row, {chol(k,0,l,t), chol(k,-1,l,t)} of the lane's column t
     real_t minDiag[kWave];
-    // Progress counters, one writer each at any time; four to a group so that a
-    // look at them is one LDS read.  Slot i (block N-1-i), row R counts as row_seq(i, R).
-    //   done[0]  wave 1: products of row 1 for the urgent rows made (i + 1)
-    //   done[1]  wave 2: products of a row for every row of the block above made (row_seq)
-    //   done[2]  wave 3: rows of slot i taken out of frow / brow (i + 1)
-    //   done[3]  wave 1: num0 written (i + 1)
-    //   rows[0]  wave 0: row of the diagonal block published (row_seq)
-    //   rows[1]  wave 1: row 11 .. 1 of the sub-diagonal block published (row_seq)
-    //   rows[2]  row 0 of the sub-diagonal block published (i + 1): wave 0, or wave 1 for a stored block
-    //   rows[3]  wave 0: the sweep is given up
-    __attribute__((aligned(16))) int done[4];
-    __attribute__((aligned(16))) int rows[4];
+    // [0] blocks handed over by wave 0, [1] blocks taken by wave 1, [3] the sweep is given up
+    __attribute__((aligned(16))) int count[4];
 #ifdef NMPC_SOLVE_STATS
     long long waited[kWaves], looked[kWaves];     // per wavefront: cycles and looks spent in waits
 #endif
@@ -589,448 +550,163 @@ struct WaitClock {
 #define NMPC_WAIT_LOOK()
 #endif
 
-NMPC_DEV constexpr int row_seq(int i, int R) { return i * 16 + (NX - R); }
-
-// Counters and what they guard are read and written as LDS accesses proper (a
-// volatile access through a generic pointer would go the flat way and wait for
-// every load in flight).
+// Counters are read and written as LDS accesses proper (a volatile access through
+// a generic pointer would go the flat way and wait for every load in flight).
 #define NMPC_LDS __attribute__((address_space(3)))
 NMPC_DEV flags4 peek(const int* group) { return *(const volatile NMPC_LDS flags4*)group; }
-NMPC_DEV real_t peek_value(const real_t* at) { return *(const volatile NMPC_LDS real_t*)at; }
 // After the data it stands for (the compiler keeps the order, the LDS does the rest).
 NMPC_DEV void post(int* counter, int value) {
     asm volatile("" ::: "memory");
     *(volatile NMPC_LDS int*)counter = value;
     asm volatile("" ::: "memory");
 }
-// Every wait looks at rows[3] as well and ends when the sweep is given up, and no
-// wait goes on for ever: after kPatience looks (a tenth of a second, where a
-// counter normally is there at the first look) the sweep is given up from here.
+// Until count[WHICH] >= value; false when the sweep is given up.  No wait goes on
+// for ever: after kPatience looks (a tenth of a second, where the counter normally
+// is there at the first) the sweep is given up from here.
 constexpr int kPatience = 1 << 21;
-NMPC_DEV bool out_of_patience(Shared& sh, int& looks) {
-    if (++looks < kPatience) return false;
-    post(&sh.rows[3], 2);
-    return true;
-}
-// Until rows[A] >= a and rows[B] >= b; false when the sweep is given up.
-template <int A, int B>
-NMPC_DEV bool await_rows(Shared& sh, int a, int b) {
-#ifdef NMPC_TEAM_SOLO
-    return true;
-#endif
+template <int WHICH>
+NMPC_DEV bool await(Shared& sh, int value) {
     NMPC_WAIT_CLOCK(sh);
     for (int looks = 0;;) {
         NMPC_WAIT_LOOK();
-        const flags4 f = peek(sh.rows);
+        const flags4 f = peek(sh.count);
         if (f[3] != 0) return false;
-        if (f[A] >= a && f[B] >= b) return true;
-        if (out_of_patience(sh, looks)) return false;
-    }
-}
-// Until done[A] >= a and done[B] >= b.
-template <int A, int B>
-NMPC_DEV bool await_done(Shared& sh, int a, int b) {
-#ifdef NMPC_TEAM_SOLO
-    return true;
-#endif
-    NMPC_WAIT_CLOCK(sh);
-    for (int looks = 0;;) {
-        NMPC_WAIT_LOOK();
-        const flags4 f = peek(sh.done);
-        if (f[A] >= a && f[B] >= b) return true;
-        if (peek(sh.rows)[3] != 0 || out_of_patience(sh, looks)) return false;
-    }
-}
-NMPC_DEV bool await_taken(Shared& sh, int i) {       // frow / brow of slot i - 2 are free again
-    return i < 2 || await_done<2, 2>(sh, i - 1, 0);
-}
-
-// Products of the block below for row JJ of the block above: only the columns
-// t <= JJ of each group use them, 4 (JJ + 1) lanes; their pairs (l, l + 1) lie lane
-// after lane, sixteen bytes each, so that neither the reads nor the writes of a
-// wavefront collide in the LDS banks.  In doubles: first pair of (row JJ, lane).
-template <int JJ>
-NMPC_DEV int c_slot(int g, int t) {
-    constexpr int T = JJ * (JJ + 1) / 2;                    // (row, column) pairs of the rows before
-    return T * kGroupsPerWave * NX + 2 * (g * (JJ + 1) + t);
-}
-// Per lane and row: where the lane reads its twelve products (any valid place
-// right of the diagonal, where nothing uses them) and where it writes them
-// (right of the diagonal: into the spare words behind the products).
-struct Slots { int at[NX]; };
-template <int... JJ>
-NMPC_DEV Slots read_slots(int g, int t, std::integer_sequence<int, JJ...>) {
-    return Slots{{c_slot<JJ>(g, t < JJ ? t : JJ)...}};
-}
-template <int... JJ>
-NMPC_DEV Slots write_slots(int g, int t, int lane, std::integer_sequence<int, JJ...>) {
-    return Slots{{(t <= JJ ? c_slot<JJ>(g, t) : kProducts + 2 * lane)...}};
-}
-
-template <int JJ>
-NMPC_DEV void read_products(const real_t* cbuf, const Slots& rd, real_t (&cc)[NX]) {
-    const real_t* at = cbuf + rd.at[JJ];
-#pragma unroll
-    for (int l = 0; l < NX / 2; l++) {
-        const pair_a v = *(const pair_a*)(at + l * c_pair_stride(JJ));
-        cc[2 * l] = v.x;
-        cc[2 * l + 1] = v.y;
-    }
-}
-
-// Products of row R of a sub-diagonal block, ls this lane's entry, with its entries
-// in the columns FIRST + J...: what row FIRST + J of the block above subtracts as
-// its term R.
-template <int JJ>
-NMPC_DEV void row_product(real_t* cbuf, const Slots& w, real_t ls, int R) {
-    cbuf[w.at[JJ] + (R / 2) * c_pair_stride(JJ) + (R & 1)] = ls * row_bcast<JJ>(ls);
-}
-template <int FIRST, int... J>
-NMPC_DEV void row_products(real_t* cbuf, const Slots& w, real_t ls, int R, std::integer_sequence<int, J...>) {
-    (row_product<FIRST + J>(cbuf, w, ls, R), ...);
-}
-using SeqUrgent = std::make_integer_sequence<int, kUrgent>;
-
-// ---- wave 0 ----------------------------------------------------------------
-// Item I of the products of row JJ with the rows below it: L[l][t] * L[l][JJ], l = JJ + 2 + I.
-template <int JJ, int I>
-NMPC_DEV void make_a(real_t (&qa)[NX], const real_t (&L)[NX]) {
-    if constexpr (JJ >= 0 && JJ + 2 + I < NX) {
-        constexpr int l = JJ + 2 + I;
-        qa[l] = L[l] * row_bcast<JJ>(L[l]);
-        NMPC_PIN(qa[l]);
-    }
-}
-
-template <int JJ, int S>
-NMPC_DEV void factor_chain_step(real_t& sum, const real_t (&pa)[NX], real_t (&qa)[NX],
-                                const real_t (&cc)[NX], const real_t (&L)[NX]) {
-    constexpr int nA = JJ + 2 < NX ? NX - 2 - JJ : 0;
-    if constexpr (S < nA) sum -= pa[JJ + 2 + S];
-    else sum -= cc[S - nA];
-    NMPC_PIN(sum);
-    make_a<JJ - 1, S>(qa, L);
-}
-
-template <int JJ, int... S>
-NMPC_DEV void factor_chain(real_t& sum, const real_t (&pa)[NX], real_t (&qa)[NX], const real_t (&cc)[NX],
-                           const real_t (&L)[NX], std::integer_sequence<int, S...>) {
-    (factor_chain_step<JJ, S>(sum, pa, qa, cc, L), ...);
-}
-
-struct FactorState {
-    bool watch;         // the lane's group factorises this block for good (a failure counts)
-    bool bad;           // a failed pivot, or a root the reciprocal is not good for, in this block
-    bool bail;
-};
-
-// Row JJ of the diagonal block of slot i: on entry cc holds the products of the
-// block below for this row, pa this row's products with the rows below it; on
-// exit they hold those of row JJ - 1.  prevSeq: what done[1] shows once every
-// product of the block below is made.
-template <int JJ>
-NMPC_DEV void factor_row(Shared& sh, int par, int i, int prevSeq, const real_t* cbuf, real_t* cout,
-                         const Slots& rd, const Slots& wr, const real_t (&Hd)[NX], real_t (&L)[NX],
-                         real_t (&pa)[NX], real_t (&cc)[NX], int t, int lane, FactorState& fs) {
-    constexpr int nA = JJ + 2 < NX ? NX - 2 - JJ : 0;
-    real_t sum = Hd[JJ];
-    if constexpr (JJ + 1 < NX) {
-        sum -= L[JJ + 1] * row_bcast<JJ>(L[JJ + 1]);        // the row just finished
-        NMPC_PIN(sum);
-    }
-    // the numerator of the sub-diagonal block's last row: asked for now, looked at below
-    flags4 seen{0, 0, 0, 0};
-    real_t num = 0.;
-    if constexpr (JJ == 0) {
-        seen = peek(sh.done);
-        num = peek_value(&sh.num0[par][lane]);
-    }
-    real_t cn[NX];
-    if constexpr (JJ > 0) {
-        // the first row past the urgent ones needs every product of the block below
-        if constexpr (JJ - 1 == NX - 1 - kUrgent) {
-            if (prevSeq > 0 && !fs.bail && !await_done<1, 1>(sh, prevSeq, 0)) fs.bail = true;
-        }
-        read_products<JJ - 1>(cbuf, rd, cn);
-    }
-    real_t qa[NX];
-    factor_chain<JJ>(sum, pa, qa, cc, L, std::make_integer_sequence<int, nA + NX>{});
-    const real_t piv = row_bcast<JJ>(sum);
-    const Pivot pv = root_and_reciprocal(piv);
-    const real_t ld = divide<true>(sum, pv);
-    // a failed pivot (dual_qp.c:859-861) or a root the reciprocal is not good for
-    fs.bad = fs.bad || (fs.watch && (piv < 1.e2 * kEqTol || (uint32_t)__double_as_longlong(pv.d) == 0xffffffffu));
-    if constexpr (JJ == 0) {
-        // given up before the block's last row is published, so that wave 3 stores nothing of it
-        if (__any(fs.bad) && !fs.bail) {
-            post(&sh.rows[3], 1);
-            fs.bail = true;
+        if (f[WHICH] >= value) return true;
+        if (++looks >= kPatience) {
+            post(&sh.count[3], 2);
+            return false;
         }
     }
-    L[JJ] = (t == JJ) ? pv.d : ld;
-    pair_a out;
-    out.x = L[JJ];
-    out.y = pv.y;
-    sh.frow[par][JJ][lane] = out;
-    post(&sh.rows[0], row_seq(i, JJ));
-    if constexpr (JJ > 0) {
-#pragma unroll
-        for (int l = JJ + 1; l < NX; l++) pa[l] = qa[l];
-#pragma unroll
-        for (int l = 0; l < NX; l++) cc[l] = cn[l];
-    } else {
-        // row 0 of the sub-diagonal block, and what the block above needs of it at once
-        NMPC_WAIT_CLOCK(sh);
-#ifdef NMPC_TEAM_SOLO
-        seen[3] = i + 1;
-#endif
-        for (int looks = 0; seen[3] < i + 1 && !fs.bail;) {
-            NMPC_WAIT_LOOK();
-            seen = peek(sh.done);
-            num = peek_value(&sh.num0[par][lane]);
-            if (peek(sh.rows)[3] != 0 || out_of_patience(sh, looks)) fs.bail = true;
-        }
-        const real_t ls0 = divide<true>(num, pv);
-        sh.brow[par][0][lane] = ls0;
-        post(&sh.rows[2], i + 1);
-        row_products<NX - kUrgent>(cout, wr, ls0, 0, SeqUrgent{});
-    }
 }
 
-template <int... R>
-NMPC_DEV void factor_rows(Shared& sh, int par, int i, int prevSeq, const real_t* cbuf, real_t* cout,
-                          const Slots& rd, const Slots& wr, const real_t (&Hd)[NX], real_t (&L)[NX],
-                          int t, int lane, FactorState& fs, std::integer_sequence<int, R...>) {
-    real_t pa[NX], cc[NX];
-    read_products<NX - 1>(cbuf, rd, cc);
-    (factor_row<NX - 1 - R>(sh, par, i, prevSeq, cbuf, cout, rd, wr, Hd, L, pa, cc, t, lane, fs), ...);
-}
-
-// ---- wave 1 ----------------------------------------------------------------
-// Row R >= 1 of the sub-diagonal block once row R of the diagonal block is
-// published: its quotient, then the chain of row R - 1 up to the division.  sub
-// holds the numerator of row R on entry and that of row R - 1 on exit.  Row 0's
-// numerator goes to wave 0, which has the pivot first; row 1's products for the
-// rows the block above starts with are made here, wave 2 would be late with them.
-template <int R>
-NMPC_DEV bool sub_row(Shared& sh, int par, int i, real_t* cbuf, const Slots& wr, const real_t (&Hs)[NX],
-                      real_t (&L)[NX], real_t (&Ls)[NX], real_t& sub, int lane) {
-    NMPC_PIN(sub);                          // the numerator is ready before the pivot is
-    if (!await_rows<0, 0>(sh, row_seq(i, R), 0)) return false;
-    const pair_a in = sh.frow[par][R][lane];
-    L[R] = in.x;
-    const Pivot pv{row_bcast<R>(in.x), in.y};
-    Ls[R] = divide<true>(sub, pv);
-    sh.brow[par][R][lane] = Ls[R];
-    post(&sh.rows[1], row_seq(i, R));
-    sub = Hs[R - 1];
-#pragma unroll
-    for (int l = R; l < NX; l++) sub -= Ls[l] * row_bcast<R - 1>(L[l]);
-    if constexpr (R == 1) {
-        sh.num0[par][lane] = sub;
-        post(&sh.done[3], i + 1);
-        row_products<NX - kUrgent>(cbuf, wr, Ls[1], 1, SeqUrgent{});
-        post(&sh.done[0], i + 1);
-    }
-    return true;
-}
-
-template <int... R>
-NMPC_DEV bool sub_rows(Shared& sh, int par, int i, real_t* cbuf, const Slots& wr, const real_t (&Hs)[NX],
-                       real_t (&L)[NX], real_t (&Ls)[NX], int lane, std::integer_sequence<int, R...>) {
-    real_t sub = Hs[NX - 1];
-    return (sub_row<NX - 1 - R>(sh, par, i, cbuf, wr, Hs, L, Ls, sub, lane) && ...);
-}
-
-// ---- wave 2 ----------------------------------------------------------------
-template <int R>
-NMPC_DEV bool prod_row(Shared& sh, int par, int i, const Slots& wr, int lane) {
-    if (R > 0 ? !await_rows<1, 1>(sh, row_seq(i, R), 0) : !await_rows<2, 2>(sh, i + 1, 0)) return false;
-    row_products<0>(sh.cprod[par], wr, sh.brow[par][R][lane], R, Seq12{});
-    post(&sh.done[1], row_seq(i, R));
-    return true;
-}
-template <int... R>
-NMPC_DEV bool prod_rows(Shared& sh, int par, int i, const Slots& wr, int lane, std::integer_sequence<int, R...>) {
-    return (prod_row<NX - 1 - R>(sh, par, i, wr, lane) && ...);
-}
-
-// ---- wave 3 ----------------------------------------------------------------
-template <bool FAST, int R>
-NMPC_DEV void subst_row(bool storeM, bool storeSub, real_t* cholRow, real_t (&xk)[NX], real_t& mine,
-                        const real_t (&L)[NX], const real_t (&Ls)[NX], const real_t (&pn)[NX], real_t gm,
-                        const Pivot& dd, int t) {
-    backsolve_row<FAST, R>(xk, mine, L, pn, gm, dd, t);
-    if (storeM) {
-        if (R >= t) cholRow[kCholDiagRow[R] + t] = L[R];
-        if (storeSub) cholRow[NX * R + t] = Ls[R];
-    }
-}
-
-template <bool FAST, int... R>
-NMPC_DEV void subst_rows(bool storeM, bool storeSub, real_t* cholRow, real_t (&xk)[NX], real_t& mine,
-                         const real_t (&L)[NX], const real_t (&Ls)[NX], const real_t (&pn)[NX], real_t gm,
-                         const Pivot& dd, int t, std::integer_sequence<int, R...>) {
-    (subst_row<FAST, NX - 1 - R>(storeM, storeSub, cholRow, xk, mine, L, Ls, pn, gm, dd, t), ...);
-}
-
-// The sweep, slot i = 0 .. N-1 for block k = N-1-i, every wavefront at its own
-// pace.  Returns true when the sweep was given up (`bail`); minDiag as
-// backward_pass leaves it.
-NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bool active, int role,
-                    int lane, real_t& minDiag) {
+// Wave 0: backward_pass without the substitution and the stores; block rows are
+// fetched one block ahead into registers.
+NMPC_DEV void factor_sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bool active, int lane) {
     const int N = v.N;
-    const int g = lane >> 4, t = lane & 15;
+    const int t = lane & 15;
     const bool col = t < NX;
     const int tc = col ? t : 0;
-    const int maxStart = wave_max(active ? start : -1);     // blocks k <= maxStart are factorised by all
-    // the block below the last one is empty: its products are +0, and x - (+0) = x
-    {
-        real_t* c0 = sh.cprod[N & 1];
-        for (int i = threadIdx.x; i < kProducts; i += kWaves * kWave) c0[i] = 0.;
-        if (threadIdx.x < 4) { sh.done[threadIdx.x] = 0; sh.rows[threadIdx.x] = 0; }
-#ifdef NMPC_SOLVE_STATS
-        if (threadIdx.x < kWaves) { sh.waited[threadIdx.x] = 0; sh.looked[threadIdx.x] = 0; }
+    real_t Ln[NX], nL[NX], nLs[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) { Ln[j] = 0.; nL[j] = 0.; nLs[j] = 0.; }
+    auto fetch_block_row = [&](bool fromH, int kk) {
+        if (!active) return;
+        // one load per value, its place chosen between the two layouts
+        const real_t* row = (fromH ? I.hess + (size_t)kk * (2 * NX * NX) : I.chol + (size_t)kk * kCholRow) + tc;
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            nL[l] = row[fromH ? l * 2 * NX + NX : kCholDiagRow[l]];
+            nLs[l] = row[fromH ? l * 2 * NX : NX * l];
+        }
+    };
+    bool nextFromHess = __any(active && N - 1 <= start);
+    fetch_block_row(nextFromHess, N - 1);
+    for (int k = N - 1; k >= 0; --k) {
+        const int i = N - 1 - k;
+        const bool fromHess = nextFromHess;
+        real_t L[NX], Ls[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) { L[l] = nL[l]; Ls[l] = nLs[l]; }
+        if (k > 0) {
+            nextFromHess = __any(active && k - 1 <= start);
+            fetch_block_row(nextFromHess, k - 1);
+        }
+        if (fromHess) {
+            int failCol = -1;
+            uint32_t ones = 0;
+            real_t dd = 1.;
+            factor_columns<true>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
+            bool bad = active && ((k <= start && failCol >= 0) || ones == 0xffffffffu);
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: give up half-way through every sweep
+            bad = bad || k == N / 2;
 #endif
+            if (__any(bad)) {           // before the block is handed over: wave 1 stores nothing of it
+                post(&sh.count[3], 1);
+                return;
+            }
+        }
+        // wave 1 has taken the block row before last out of this buffer
+        if (i >= 2 && !await<1>(sh, i - 1)) return;
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            pair_a out;
+            out.x = L[l];
+            out.y = Ls[l];
+            sh.row[k & 1][l][lane] = out;
+        }
+        post(&sh.count[0], i + 1);
+#pragma unroll
+        for (int j = 0; j < NX; j++) Ln[j] = Ls[j];
     }
+}
+
+// Wave 1: the bottom-up substitution of block m once its rows are there, and the
+// stores of the rows that were factorised.
+NMPC_DEV void substitution_sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bool active,
+                                 int lane, real_t& minDiag) {
+    const int N = v.N;
+    const int t = lane & 15;
+    const bool col = t < NX;
+    const int tc = col ? t : 0;
+    real_t L[NX], Ls[NX], xk[NX], pn[NX];
+#pragma unroll
+    for (int l = 0; l < NX; l++) { xk[l] = 0.; pn[l] = 0.; }
+    real_t ng = active ? I.grad[(N - 1) * NX + tc] : 0.;
+    for (int i = 0; i < N; ++i) {
+        const int m = N - 1 - i;
+        const real_t gm = ng;
+        if (m > 0 && active) ng = I.grad[(m - 1) * NX + tc];
+        if (!await<0>(sh, i + 1)) return;
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            const pair_a in = sh.row[m & 1][l][lane];
+            L[l] = in.x;
+            Ls[l] = in.y;
+        }
+        const real_t own = sh.row[m & 1][tc][lane].x;       // chol(m,0,t,t)
+        post(&sh.count[1], i + 1);
+        const real_t dd = active ? own : 1.;
+        if (col && minDiag > dd) minDiag = dd;
+        const Pivot pv{dd, 1.0 / dd};
+        real_t mine = 0.;
+        if (__any(plain_division_needed(dd)))
+            backsolve_rows<false>(xk, mine, L, pn, gm, pv, t, Seq12{});
+        else
+            backsolve_rows<true>(xk, mine, L, pn, gm, pv, t, Seq12{});
+        if (active && col) {
+            // into scratch: the step itself is only written once the factor is known to be good
+            I.tmp[m * NX + t] = mine;
+            if (m <= start) {
+                real_t* row = I.chol + (size_t)m * kCholRow;
+#pragma unroll
+                for (int l = 0; l < NX; l++)
+                    if (l >= t) row[kCholDiagRow[l] + t] = L[l];
+                if (m > 0) {
+#pragma unroll
+                    for (int l = 0; l < NX; l++) row[NX * l + t] = Ls[l];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NX; j++) pn[j] = Ls[j] * xk[j];
+    }
+}
+
+// Returns true when the sweep was given up; minDiag as backward_pass leaves it.
+NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bool active, int role,
+                    int lane, real_t& minDiag) {
+    if (threadIdx.x < 4) sh.count[threadIdx.x] = 0;
+#ifdef NMPC_SOLVE_STATS
+    if (threadIdx.x < kWaves) { sh.waited[threadIdx.x] = 0; sh.looked[threadIdx.x] = 0; }
+#endif
     __syncthreads();
 #ifdef NMPC_SOLVE_STATS
     const long long sweep0 = clock64();
 #endif
-
-    const Slots rd = read_slots(g, tc, Seq12{});
-    const Slots wr = write_slots(g, t, lane, Seq12{});
-    // Column tc of block row kk: from the Newton Hessian when the block is
-    // factorised, from the stored factor otherwise (one load per value, its place
-    // chosen between the two layouts).  Wave 0 takes the diagonal block, wave 1
-    // the sub-diagonal block.
-    real_t nA[NX];
-#pragma unroll
-    for (int l = 0; l < NX; l++) nA[l] = 0.;
-    auto fetch = [&](int kk) {
-        if (kk < 0 || !active) return;
-        const bool fromH = kk <= maxStart;
-        const real_t* row = (fromH ? I.hess + (size_t)kk * (2 * NX * NX) : I.chol + (size_t)kk * kCholRow) + tc;
-        if (role == kFactor) {
-#pragma unroll
-            for (int l = 0; l < NX; l++) nA[l] = row[fromH ? l * 2 * NX + NX : kCholDiagRow[l]];
-        } else {
-#pragma unroll
-            for (int l = 0; l < NX; l++) nA[l] = row[fromH ? l * 2 * NX : NX * l];
-        }
-    };
-
-    bool bail = false;
-#ifdef NMPC_TEAM_SOLO       // timing experiment: wave 0 alone, nothing it waits for ever comes
-    if (role != kFactor) bail = true;
-#endif
-    if (role == kFactor) {
-        real_t L[NX];
-#pragma unroll
-        for (int l = 0; l < NX; l++) L[l] = 0.;
-        fetch(N - 1);
-        for (int i = 0; i < N && !bail; ++i) {
-            const int k = N - 1 - i, par = k & 1;
-            real_t A[NX];
-#pragma unroll
-            for (int l = 0; l < NX; l++) A[l] = nA[l];
-            fetch(k - 1);
-            if (!await_taken(sh, i)) { bail = true; break; }
-            if (k <= maxStart) {
-                // products of the block below: all of them when it was a stored block,
-                // else rows 2 .. 11 from wave 2, row 1's urgent ones from wave 1 (row 0's are this wave's own)
-                int prevSeq = 0;
-                if (i > 0) {
-                    const bool belowFactorised = k + 1 <= maxStart;
-                    prevSeq = row_seq(i - 1, 0);
-                    const int needProd = belowFactorised ? row_seq(i - 1, 2) : prevSeq;
-                    const int needUrgent = belowFactorised ? i : 0;
-                    if (!await_done<1, 0>(sh, needProd, needUrgent)) { bail = true; break; }
-                }
-#ifdef NMPC_TEAM_SOLO
-                FactorState fs{false, false, false};
-#else
-                FactorState fs{active && k <= start, false, false};
-#endif
-                factor_rows(sh, par, i, prevSeq, sh.cprod[par ^ 1], sh.cprod[par], rd, wr, A, L, t, lane, fs, Seq12{});
-                bail = fs.bail;
-#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: give up half-way through every sweep
-                if (k == N / 2 && !bail) { post(&sh.rows[3], 1); bail = true; }
-#endif
-            } else {
-#pragma unroll
-                for (int l = 0; l < NX; l++) {
-                    pair_a out;
-                    out.x = A[l];
-                    out.y = 0.;
-                    sh.frow[par][l][lane] = out;
-                }
-                post(&sh.rows[0], row_seq(i, 0));
-            }
-        }
-    } else if (role == kSub) {
-        real_t L[NX], Ls[NX];
-#pragma unroll
-        for (int l = 0; l < NX; l++) { L[l] = 0.; Ls[l] = 0.; }
-        fetch(N - 1);
-        for (int i = 0; i < N && !bail; ++i) {
-            const int k = N - 1 - i, par = k & 1;
-            real_t A[NX];
-#pragma unroll
-            for (int l = 0; l < NX; l++) A[l] = nA[l];
-            fetch(k - 1);
-            if (k <= maxStart) {
-                bail = !sub_rows(sh, par, i, sh.cprod[par], wr, A, L, Ls, lane, std::make_integer_sequence<int, NX - 1>{});
-            } else {
-                if (!await_taken(sh, i)) { bail = true; break; }
-#pragma unroll
-                for (int l = 0; l < NX; l++) sh.brow[par][l][lane] = A[l];
-                post(&sh.rows[1], row_seq(i, 1));
-                post(&sh.rows[2], i + 1);
-            }
-        }
-    } else if (role == kProd) {
-        // only the block right below a factorised one is asked for its products
-        for (int i = 0; i < N - 1 && !bail; ++i) {
-            const int k = N - 1 - i;
-            if (k - 1 <= maxStart) bail = !prod_rows(sh, k & 1, i, wr, lane, Seq12{});
-        }
+    if (role == 0) {
+        factor_sweep(sh, v, I, start, active, lane);
     } else {
-        real_t L[NX], Ls[NX], xk[NX], pn[NX];
-#pragma unroll
-        for (int l = 0; l < NX; l++) { xk[l] = 0.; pn[l] = 0.; }
-        real_t ng = active ? I.grad[(N - 1) * NX + tc] : 0.;
-        for (int i = 0; i < N && !bail; ++i) {
-            const int m = N - 1 - i, par = m & 1;
-            const real_t gm = ng;
-            if (m > 0 && active) ng = I.grad[(m - 1) * NX + tc];
-            if (!await_rows<0, 2>(sh, row_seq(i, 0), i + 1)) { bail = true; break; }
-            // block m is complete: the lane's column of both blocks, its own pivot
-#pragma unroll
-            for (int l = 0; l < NX; l++) {
-                L[l] = sh.frow[par][l][lane].x;
-                Ls[l] = sh.brow[par][l][lane];
-            }
-            const pair_a own = sh.frow[par][tc][lane];
-            NMPC_PIN(L[0]);
-            post(&sh.done[2], i + 1);
-            const bool mFromHess = m <= maxStart;
-            Pivot dd;
-            dd.d = active ? own.x : 1.;
-            dd.y = mFromHess ? own.y : 1.0 / dd.d;
-            if (col && minDiag > dd.d) minDiag = dd.d;
-            const bool storeM = active && col && m <= start;
-            real_t* cholRow = I.chol + (size_t)m * kCholRow;
-            real_t mine = 0.;
-            if (!mFromHess && __any(plain_division_needed(dd.d)))
-                subst_rows<false>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
-            else
-                subst_rows<true>(storeM, m > 0, cholRow, xk, mine, L, Ls, pn, gm, dd, t, Seq12{});
-            // into scratch: the step itself is only written once the factor is known to be good
-            if (active && col) I.tmp[m * NX + t] = mine;
-#pragma unroll
-            for (int j = 0; j < NX; j++) pn[j] = Ls[j] * xk[j];
-        }
+        substitution_sweep(sh, v, I, start, active, lane, minDiag);
         sh.minDiag[lane] = minDiag;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the factor and the scratch are stored
     }
@@ -1043,8 +719,8 @@ NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bo
     }
 #endif
     __syncthreads();
-    if (role == kFactor) minDiag = sh.minDiag[lane];
-    return sh.rows[3] != 0;
+    if (role == 0) minDiag = sh.minDiag[lane];
+    return sh.count[3] != 0;
 }
 
 }  // namespace team
@@ -1142,7 +818,7 @@ void k_newton_solve(BatchView v, int teamBeside) {
 }
 
 #ifndef NMPC_SINGLE_PRECISION
-// The same solve with the first bottom-up sweep run by a team of four wavefronts
+// The same solve with the first bottom-up sweep run by a team of two wavefronts
 // (namespace team); regularised second sweeps, sweeps the team gives up, and the
 // top-down substitution are wave 0's alone, through the code of k_newton_solve.
 __global__ __launch_bounds__(team::kWaves * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -1156,7 +832,7 @@ void k_newton_solve_team(BatchView v) {
     const int first = blockIdx.x * kGroupsPerWave;
     const int b0 = launch_instance(v, first);
     if (b0 < 0) return;
-    if (role == team::kFactor) __builtin_amdgcn_s_setprio(3);
+    if (role == 0) __builtin_amdgcn_s_setprio(3);
     const int bg = launch_instance(v, first + g);
     const bool have = bg >= 0;
     const int b = have ? bg : b0;
@@ -1169,7 +845,7 @@ void k_newton_solve_team(BatchView v) {
 
     real_t minDiag = kInfty;
     const bool gaveUp = team::sweep(sh, v, I, start, live, role, lane, minDiag);
-    if (role != team::kFactor) return;
+    if (role != 0) return;
     int st = ST_OK;
     if (gaveUp) {
         minDiag = kInfty;
@@ -1323,14 +999,14 @@ BatchView solve_list_view(const BatchView& v, unsigned epoch, int part) {
 }
 
 // The team form pays where it leaves no SIMD short of work: an unlisted launch of at
-// most one team per CU, or the long-sweep part of a two-part iteration (whose
+// most two teams per CU, or the long-sweep part of a two-part iteration (whose
 // length only the device knows: both kernels are launched and the list's length
-// decides which of them works).  Off unless NMPC_TEAM is set.
+// decides which of them works).  NMPC_NO_TEAM=1 keeps the one-wavefront form.
 static bool team_wanted(const BatchView& v) {
 #ifdef NMPC_SINGLE_PRECISION
     return false;
 #else
-    static const bool off = getenv("NMPC_TEAM") == nullptr;     // opt-in while it is being measured
+    static const bool off = getenv("NMPC_NO_TEAM") != nullptr;
     if (off || newton_solve_two_waves(v)) return false;
     if (v.list) return v.listPart == 1;
     return v.nb <= team::kMaxInstances;

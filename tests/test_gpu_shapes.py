@@ -172,3 +172,24 @@ def test_one_part_iterations_in_a_fresh_process(port_built):
     assert len(lines) == 2, out.stdout[-2000:]
     for l in lines:
         assert " 0 mismatches" in l and "0 entries differ" in l, l
+
+
+def test_one_wavefront_sweep_in_a_fresh_process(port_built):
+    """NMPC_NO_TEAM keeps the Newton solve's bottom-up sweep in one wavefront
+    where the library otherwise runs it as a team of two (batches of up to 2 048
+    instances and the long-sweep part of two-part iterations): same results,
+    checked by the soak tool in a child process because the switch is read once
+    per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMPC_NO_TEAM="1", SOAK_DUMPS="8")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "soak_warm.py"),
+                          "777", "30", "3", "5151", "96", "100", "3", "5153"],
+                         env=env, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "mismatches" in l]
+    assert len(lines) == 2, out.stdout[-2000:]
+    for l in lines:
+        assert " 0 mismatches" in l and "0 entries differ" in l, l

@@ -25,7 +25,7 @@ for rep in range(3):
     bt.solve(d["meas"][:, 0]); bt.get_controls()
     torch.cuda.synchronize()
     lib.nmpc_debug_team_stats(out, 1)
-    for role, name in enumerate(("factor", "sub", "products", "substitution")):
+    for role, name in enumerate(("factor", "substitution")):
         n = out[role * 4 + 3]
         if n:
             print("team wave %d %-12s sweeps %5d  cycles %9.0f  of them waiting %9.0f  looks %8.0f"
