@@ -154,6 +154,22 @@ int nmpc_batch_set_terminal_weights(nmpc_batch_t *b, const real_t coeffs[12]);
 int nmpc_batch_set_lower_control_bound(nmpc_batch_t *b, const real_t coeffs[3]);
 int nmpc_batch_set_upper_control_bound(nmpc_batch_t *b, const real_t coeffs[3]);
 
+/* The same for instances first .. first+count-1 alone, each with values of its
+ * own: the reference keeps weights and bounds per controller
+ * (ccs-c66x/cnmpc.c:988-1020), and so may the instances of a batch.  Arrays
+ * [count][12] / [count][3] in host or device memory; a null array leaves that
+ * setting as it is.  As in the reference, weights take effect at the next
+ * nmpc_batch_init (cnmpc.c:899-925); bounds are read by nmpc_batch_init, by
+ * every stage linearisation after the call and by every feedback step
+ * (cnmpc.c:920-931, 643-645, 1053-1062, 675-702).  The setters above keep
+ * writing every instance.  The first call allocates one record of 72 values
+ * per instance. */
+int nmpc_batch_set_instance_weights(nmpc_batch_t *b, uint32_t first, uint32_t count,
+                                    const real_t *state_weights, const real_t *control_weights,
+                                    const real_t *terminal_weights);
+int nmpc_batch_set_instance_control_bounds(nmpc_batch_t *b, uint32_t first, uint32_t count,
+                                           const real_t *lower, const real_t *upper);
+
 /* nmpc_init for every instance (ccs-c66x/cnmpc.c:872-948). */
 int nmpc_batch_init(nmpc_batch_t *b);
 

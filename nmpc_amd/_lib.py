@@ -88,6 +88,10 @@ def prototypes(REAL):
         "nmpc_batch_set_terminal_weights": (C.c_int, [C.c_void_p, PREAL]),
         "nmpc_batch_set_lower_control_bound": (C.c_int, [C.c_void_p, PREAL]),
         "nmpc_batch_set_upper_control_bound": (C.c_int, [C.c_void_p, PREAL]),
+        "nmpc_batch_set_instance_weights": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p]),
+        "nmpc_batch_set_instance_control_bounds": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                             C.c_void_p]),
         "nmpc_batch_init": (C.c_int, [C.c_void_p]),
         "nmpc_batch_set_wind_velocity": (C.c_int, [C.c_void_p, C.c_void_p]),
         "nmpc_batch_set_reference_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32,

@@ -98,6 +98,23 @@ class Batch:
         self._ck(self.lib.nmpc_batch_set_lower_control_bound(self.h, dp(_vec(lower_control_bound, 3))))
         self._ck(self.lib.nmpc_batch_set_upper_control_bound(self.h, dp(_vec(upper_control_bound, 3))))
 
+    def setup_instances(self, first, state_weights=None, control_weights=None, terminal_weights=None,
+                        upper_control_bound=None, lower_control_bound=None):
+        """Weights and control bounds of instances first .. first+count-1 alone:
+        arrays [count][12] / [count][3] (numpy or torch CUDA tensors), None leaves a
+        setting as it is.  Weights take effect at the next initialise_horizon()."""
+        given = [a for a in (state_weights, control_weights, terminal_weights,
+                             upper_control_bound, lower_control_bound) if a is not None]
+        if not given:
+            return
+        count = int(given[0].shape[0])
+        arg = lambda a, n: self._arg(a, (count, n)) if a is not None else None
+        ptr = lambda a: a.ptr if a is not None else None
+        wq, wr, wt = arg(state_weights, 12), arg(control_weights, 3), arg(terminal_weights, 12)
+        ub, lb = arg(upper_control_bound, 3), arg(lower_control_bound, 3)
+        self._ck(self.lib.nmpc_batch_set_instance_weights(self.h, int(first), count, ptr(wq), ptr(wr), ptr(wt)))
+        self._ck(self.lib.nmpc_batch_set_instance_control_bounds(self.h, int(first), count, ptr(lb), ptr(ub)))
+
     def initialise_horizon(self):
         self._ck(self.lib.nmpc_batch_init(self.h))
 

@@ -115,6 +115,10 @@ struct nmpc_batch {
     // looked at; clears happen only where an earlier reader turns up.
     bool stage_zero_pending = false;    // zLow, zUpp, q, z, qStep, zUnc, dz, tmp, y
     bool zy_zero_pending = false;       // z, y only (after nmpc_batch_init)
+    // [B][kCfgStride] weights and bounds of every instance, allocated by the first
+    // per-instance setter; until then every instance has the batch's (v.cfg null)
+    real_t* cfg = nullptr;
+    Staging in_cfg;
     real_t* plant = nullptr;    // [B][13] simulated vehicle states (nmpc_batch_plant_*)
     real_t* plant_next = nullptr;   // output of the next roll-forward step, then swapped
     bool profiling = false;
@@ -373,6 +377,8 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
     b->out_u.release(); b->out_status.release(); b->out_iters.release(); b->scratch.release();
     if (b->plant) (void)hipFree(b->plant);
     if (b->plant_next) (void)hipFree(b->plant_next);
+    if (b->cfg) (void)hipFree(b->cfg);
+    b->in_cfg.release();
     if (b->arena) (void)hipFree(b->arena);
     if (b->side_stream) {
         (void)hipStreamSynchronize(b->side_stream);
@@ -408,18 +414,91 @@ int nmpc_batch_synchronize(nmpc_batch_t* b) {
     return 0;
 }
 
-#define SETTER(name, field, n)                                          \
+// The batch-wide setters keep the host copy and, once instances have records of
+// their own, write the value into every record as well.
+#define SETTER(name, field, n, at)                                      \
     int name(nmpc_batch_t* b, const real_t* coeffs) {                   \
         if (!b || !coeffs) return fail(NMPC_E_ARG, #name ": null argument"); \
         memcpy(b->field, coeffs, (n) * sizeof(real_t));                 \
+        if (b->cfg) {                                                   \
+            TRY(use_device(b));                                         \
+            launch_cfg_set(b->cfg, 0, b->v.B, at, n, nullptr, b->field, b->stream); \
+            HIP_TRY(hipGetLastError());                                 \
+        }                                                               \
         return 0;                                                       \
     }
-SETTER(nmpc_batch_set_state_weights, wq, 12)
-SETTER(nmpc_batch_set_control_weights, wr, 3)
-SETTER(nmpc_batch_set_terminal_weights, wt, 12)
-SETTER(nmpc_batch_set_lower_control_bound, lb, 3)
-SETTER(nmpc_batch_set_upper_control_bound, ub, 3)
+SETTER(nmpc_batch_set_state_weights, wq, 12, kCfgWq)
+SETTER(nmpc_batch_set_control_weights, wr, 3, kCfgWr)
+SETTER(nmpc_batch_set_terminal_weights, wt, 12, kCfgWt)
+SETTER(nmpc_batch_set_lower_control_bound, lb, 3, kCfgLb)
+SETTER(nmpc_batch_set_upper_control_bound, ub, 3, kCfgUb)
 #undef SETTER
+
+namespace {
+// Records for every instance, filled with what the batch has had so far: the
+// setters' values, and what the last nmpc_batch_init latched from them.
+int ensure_cfg(nmpc_batch* b) {
+    if (b->cfg) return 0;
+    const int B = b->v.B;
+    HIP_TRY(hipMalloc((void**)&b->cfg, (size_t)B * kCfgStride * sizeof(real_t)));
+    HIP_TRY(hipMemsetAsync(b->cfg, 0, (size_t)B * kCfgStride * sizeof(real_t), b->stream));
+    const struct { int at, n; const real_t* src; } parts[] = {
+        {kCfgWq, 12, b->wq}, {kCfgWr, 3, b->wr}, {kCfgWt, 12, b->wt}, {kCfgLb, 3, b->lb}, {kCfgUb, 3, b->ub},
+        {kCfgH, 15, b->v.H}, {kCfgHt, 12, b->v.Ht}, {kCfgLb0, 3, b->init_lb}, {kCfgUb0, 3, b->init_ub}};
+    for (const auto& p : parts) launch_cfg_set(b->cfg, 0, B, p.at, p.n, nullptr, p.src, b->stream);
+    HIP_TRY(hipGetLastError());
+    b->v.cfg = b->cfg;
+    return 0;
+}
+
+// values[count][n] (host or device memory, null: leave as it is) into the records.
+int set_cfg_part(nmpc_batch* b, uint32_t first, uint32_t count, int at, int n, const real_t* values,
+                 bool* host) {
+    if (!values) return 0;
+    const void* dev = nullptr;
+    if (!is_device_pointer(values)) {
+        // one staging buffer for the parts of one call: each part behind the one before
+        *host = true;
+    }
+    TRY(stage_in(b, b->in_cfg, values, (size_t)count * n * sizeof(real_t), &dev));
+    launch_cfg_set(b->cfg, (int)first, (int)count, at, n, (const real_t*)dev, nullptr, b->stream);
+    HIP_TRY(hipGetLastError());
+    // the staging buffer is reused by the next part
+    if (!is_device_pointer(values)) HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+}  // namespace
+
+int nmpc_batch_set_instance_weights(nmpc_batch_t* b, uint32_t first, uint32_t count, const real_t* state,
+                                    const real_t* control, const real_t* terminal) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    if ((uint64_t)first + count > (uint64_t)b->v.B)
+        return fail(NMPC_E_ARG, "nmpc_batch_set_instance_weights: instances %u..%u beyond the batch's %d",
+                    first, first + count - 1, b->v.B);
+    if (count == 0) return 0;
+    TRY(use_device(b));
+    TRY(ensure_cfg(b));
+    bool host = false;
+    TRY(set_cfg_part(b, first, count, kCfgWq, 12, state, &host));
+    TRY(set_cfg_part(b, first, count, kCfgWr, 3, control, &host));
+    TRY(set_cfg_part(b, first, count, kCfgWt, 12, terminal, &host));
+    return 0;
+}
+
+int nmpc_batch_set_instance_control_bounds(nmpc_batch_t* b, uint32_t first, uint32_t count,
+                                           const real_t* lower, const real_t* upper) {
+    if (!b) return fail(NMPC_E_ARG, "null batch");
+    if ((uint64_t)first + count > (uint64_t)b->v.B)
+        return fail(NMPC_E_ARG, "nmpc_batch_set_instance_control_bounds: instances %u..%u beyond the batch's %d",
+                    first, first + count - 1, b->v.B);
+    if (count == 0) return 0;
+    TRY(use_device(b));
+    TRY(ensure_cfg(b));
+    bool host = false;
+    TRY(set_cfg_part(b, first, count, kCfgLb, 3, lower, &host));
+    TRY(set_cfg_part(b, first, count, kCfgUb, 3, upper, &host));
+    return 0;
+}
 
 int nmpc_batch_init(nmpc_batch_t* b) {
     if (!b) return fail(NMPC_E_ARG, "null batch");
@@ -433,6 +512,10 @@ int nmpc_batch_init(nmpc_batch_t* b) {
     sync_config(b);
     memcpy(b->init_lb, b->lb, sizeof b->init_lb);
     memcpy(b->init_ub, b->ub, sizeof b->init_ub);
+    if (b->cfg) {       // the same, instance by instance
+        launch_cfg_latch(b->cfg, v.B, b->stream);
+        HIP_TRY(hipGetLastError());
+    }
     v.head = 0;   // the interval order is rebuilt (ccs-c66x/cnmpc.c:817-828)
     // Jacobians and residuals start at zero (ccs-c66x/cnmpc.c:913-917)
     b->jacobians_zero_pending = true;

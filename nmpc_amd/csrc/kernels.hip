@@ -104,6 +104,8 @@ __global__ void k_store_refs(BatchView v, const real_t* __restrict__ refs,
 // stage at once (part 1), the stages 0..N-1 (part 2) only if something turns up
 // that reads them before every stage has been linearised.  Part 3 is part 1 for
 // the instances whose last solve converged (real-time-iteration preparation).
+// OWN: every instance has weights and control bounds of its own (BatchView::cfg).
+template <bool OWN>
 __global__ void k_init_stages(BatchView v, int part) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = (v.N + 1) * NZ;
@@ -120,7 +122,6 @@ __global__ void k_init_stages(BatchView v, int part) {
     const int nV = k < v.N ? NZ : NX;
     if (i >= nV) return;
     const int s = stage_slot(v, k);
-    const real_t* H = stage_hessian(v, k);
     real_t qs = 0., ps = 0.;
     if (k < v.N) {
         const real_t* l1 = I.lam + (size_t)lam_slot(v, k) * NX;
@@ -135,12 +136,19 @@ __global__ void k_init_stages(BatchView v, int part) {
     const real_t qv = qs + 0.0;
     const int e = s * NZ + i;
     I.qStep[e] = qv;
-    const real_t d = qv / H[i];
+    const real_t* own = v.cfg + (size_t)b * kCfgStride;         // OWN only
+    real_t h;
+    if constexpr (OWN) h = own[(k < v.N ? kCfgH : kCfgHt) + i];
+    else h = stage_hessian(v, k)[i];
+    const real_t d = qv / h;
     I.dz[e] = -d;
     I.zUnc[e] = 0.0;
     I.q[e] = 0.0;
     real_t lo = -kInfty, up = kInfty;
-    if (i >= NX) { lo = v.lb[i - NX]; up = v.ub[i - NX]; }
+    if (i >= NX) {      // the control bounds nmpc_init saw
+        if constexpr (OWN) { lo = own[kCfgLb0 + i - NX]; up = own[kCfgUb0 + i - NX]; }
+        else { lo = v.lb[i - NX]; up = v.ub[i - NX]; }
+    }
     I.zLow[e] = lo;
     I.zUpp[e] = up;
 }
@@ -182,6 +190,8 @@ struct LineariseLds {
     real_t lam_prev[kStagesPerBlock][NX];   // ... to stage k - 1
     real_t z[kStagesPerBlock][NZ];          // stage solution (real-time iteration)
     real_t H[NZ], lb[NU], ub[NU];
+    // the same per stage for batches whose instances have weights and bounds of their own
+    real_t own[kStagesPerBlock][NZ + 2 * NU];
     int row[kStagesPerBlock];               // (instance, slot) row of the stage in C and c
     int inst[kStagesPerBlock], pos[kStagesPerBlock], slot[kStagesPerBlock];
 };
@@ -310,7 +320,8 @@ NMPC_DEV void store_tiles(const LineariseLds& L, int nvalid, real_t* jac, real_t
 // (the real-time-iteration preparation step; the reference has no code for it).
 // only_solved: the stages of instances whose last solve did not converge are
 // left as they are.
-template <bool ABOUT_SOLUTION>
+// OWN: every instance has weights and control bounds of its own (BatchView::cfg).
+template <bool ABOUT_SOLUTION, bool OWN>
 __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchView v, int first, int count,
                                                                          int only_solved) {
     __shared__ LineariseLds L;
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
     const long st = (long)blockIdx.x * kStagesPerBlock + g;
     bool active = g < kStagesPerBlock && st < total;
     if (active && only_solved) active = v.sc[(unsigned)st / (unsigned)count].lastResult != 0;
-    if (t == 0) {                   // kernel arguments: static indices only
+    if (!OWN && t == 0) {           // kernel arguments: static indices only
 #pragma unroll
         for (int i = 0; i < NZ; i++) L.H[i] = v.H[i];
 #pragma unroll
@@ -355,12 +366,23 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
             if (c < NZ - kLanesPerStage) L.z[g][kLanesPerStage + c] = zw;
         }
         if (c == 0) { L.row[g] = b * v.N + s; L.inst[g] = b; L.pos[g] = k; L.slot[g] = s; }
+        if (OWN) {      // latched stage Hessian, live bounds
+            const real_t* cfg = v.cfg + (size_t)b * kCfgStride;
+            L.own[g][c] = cfg[kCfgH + c];
+            if (c < NZ - kLanesPerStage) L.own[g][kLanesPerStage + c] = cfg[kCfgH + kLanesPerStage + c];
+            if (c < 2 * NU) L.own[g][NZ + c] = cfg[kCfgLb + c];
+        }
     } else if (c == 0 && g < kStagesPerBlock) {
         L.row[g] = -1;                              // no tile to store for this group
     }
     __syncthreads();
     real_t col[NX];
-    linearise_lanes<ABOUT_SOLUTION>(L, active, g, c, v.lb, v.ub, col);
+    if constexpr (OWN) {
+        const int gg = active ? g : 0;
+        linearise_lanes<ABOUT_SOLUTION>(L, active, g, c, &L.own[gg][NZ], &L.own[gg][NZ + NU], col);
+    } else {
+        linearise_lanes<ABOUT_SOLUTION>(L, active, g, c, v.lb, v.ub, col);
+    }
     real_t dot_own = 0.;                            // own column of C . lambda_{k+1}
     if (active && c > 0) {
 #pragma unroll
@@ -387,12 +409,12 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
         real_t qs = dot;
         if (k > 0 && jv < NX) qs -= L.lam_prev[g][jv];
         qs = qs + 0.0;
-        const real_t d = qs / L.H[jv];
+        const real_t d = qs / (OWN ? L.own[g][jv] : L.H[jv]);
         real_t lo = -kInfty, up = kInfty;
         if (jv >= NX) {
             const real_t uj = L.u[g][jv - NX];
-            lo = L.lb[jv - NX] - uj;
-            up = L.ub[jv - NX] - uj;
+            lo = (OWN ? L.own[g][NZ + jv - NX] : L.lb[jv - NX]) - uj;
+            up = (OWN ? L.own[g][NZ + NU + jv - NX] : L.ub[jv - NX]) - uj;
         }
         const size_t e = zrow + jv;
         // (a cold solve writes 0.3 GB of these before anything reads them)
@@ -522,6 +544,45 @@ __global__ void k_rti_reset(BatchView v) {
     else v.p[(size_t)b * (v.N + 1) + (r - v.N * NX)] = 0.;
 }
 
+// ------------------------------------------------------------------------
+// Per-instance weights and control bounds (BatchView::cfg, layout.hpp).
+// Entries [at, at + n) of the records of instances [first, first + count): from
+// values[count][n], or the same n values for every instance (one small vector in
+// the kernel argument).
+struct CfgVector { real_t v[NZ]; };
+__global__ void k_cfg_set(real_t* cfg, int first, int count, int at, int n, const real_t* values,
+                          CfgVector same) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * n) return;
+    const int b = t / n, i = t - b * n;
+    real_t x = same.v[0];
+#pragma unroll
+    for (int j = 1; j < NZ; j++) x = (i == j) ? same.v[j] : x;
+    if (values) x = values[t];
+    cfg[(size_t)(first + b) * kCfgStride + at + i] = x;
+}
+
+// nmpc_init: the stage Hessians as the solver sees them and the bounds of this
+// moment (ccs-c66x/cnmpc.c:899-931).  A weight block within 1e-15 of the identity
+// carries no data in the reference's solver and behaves as exact ones
+// (qpDUNES/utils.c:106-117, setup_qp.c:229-258); state and control weights are
+// separate blocks there, as are the terminal weights.
+__global__ void k_cfg_latch(real_t* cfg, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    real_t* r = cfg + (size_t)b * kCfgStride;
+    auto identity = [&](int at, int n) {
+        bool id = true;
+        for (int i = 0; i < n; i++) id = id && !(fabs((double)r[at + i] - 1.0) > 1e-15);
+        return id;
+    };
+    const bool idq = identity(kCfgWq, NX), idr = identity(kCfgWr, NU), idt = identity(kCfgWt, NX);
+    for (int i = 0; i < NX; i++) r[kCfgH + i] = idq ? (real_t)1. : r[kCfgWq + i];
+    for (int i = 0; i < NU; i++) r[kCfgH + NX + i] = idr ? (real_t)1. : r[kCfgWr + i];
+    for (int i = 0; i < NX; i++) r[kCfgHt + i] = idt ? (real_t)1. : r[kCfgWt + i];
+    for (int i = 0; i < NU; i++) { r[kCfgLb0 + i] = r[kCfgLb + i]; r[kCfgUb0 + i] = r[kCfgUb + i]; }
+}
+
 // ========================================================================
 // launchers
 // ========================================================================
@@ -539,16 +600,31 @@ void launch_refs_from_waypoints(int B, const real_t* wp, int W, real_t t0, real_
 }
 void launch_init_stages(const BatchView& v, int part, hipStream_t s) {
     const long n = (long)v.B * (v.N + 1) * NZ;
-    hipLaunchKernelGGL(k_init_stages, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, part);
+    if (v.cfg) hipLaunchKernelGGL(k_init_stages<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, part);
+    else hipLaunchKernelGGL(k_init_stages<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, part);
 }
 void launch_linearise(const BatchView& v, int first, int count, hipStream_t s, bool about_solution,
                       bool only_solved) {
     const unsigned blocks = blocks_for((long)v.B * count, kStagesPerBlock);
-    if (about_solution)
-        hipLaunchKernelGGL(k_linearise<true>, dim3(blocks), dim3(256), 0, s, v, first, count, 1);
+    const int only = about_solution || only_solved ? 1 : 0;
+    if (about_solution && v.cfg)
+        hipLaunchKernelGGL((k_linearise<true, true>), dim3(blocks), dim3(256), 0, s, v, first, count, only);
+    else if (about_solution)
+        hipLaunchKernelGGL((k_linearise<true, false>), dim3(blocks), dim3(256), 0, s, v, first, count, only);
+    else if (v.cfg)
+        hipLaunchKernelGGL((k_linearise<false, true>), dim3(blocks), dim3(256), 0, s, v, first, count, only);
     else
-        hipLaunchKernelGGL(k_linearise<false>, dim3(blocks), dim3(256), 0, s, v, first, count,
-                           only_solved ? 1 : 0);
+        hipLaunchKernelGGL((k_linearise<false, false>), dim3(blocks), dim3(256), 0, s, v, first, count, only);
+}
+void launch_cfg_set(real_t* cfg, int first, int count, int at, int n, const real_t* values,
+                    const real_t* same, hipStream_t s) {
+    CfgVector sv{};
+    if (same) for (int i = 0; i < n; i++) sv.v[i] = same[i];
+    hipLaunchKernelGGL(k_cfg_set, dim3(blocks_for((long)count * n, 256)), dim3(256), 0, s, cfg, first, count,
+                       at, n, values, sv);
+}
+void launch_cfg_latch(real_t* cfg, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_cfg_latch, dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, B);
 }
 void launch_rti_reset(const BatchView& v, hipStream_t s) {
     const long n = (long)v.B * (v.N * NX + v.N + 1);

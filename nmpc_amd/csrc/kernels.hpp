@@ -16,6 +16,13 @@ void launch_init_stages(const BatchView& v, int part, hipStream_t s);
 void launch_linearise(const BatchView& v, int first, int count, hipStream_t s,
                       bool about_solution = false, bool only_solved = false);
 void launch_rti_reset(const BatchView& v, hipStream_t s);
+// Per-instance weights and bounds (BatchView::cfg): entries [at, at + n) of the
+// records of instances [first, first + count) from values[count][n] (device
+// memory) or, values null, the n values of `same` (host memory) for every one of
+// them; launch_cfg_latch is nmpc_init's copy of weights and bounds into the QP.
+void launch_cfg_set(real_t* cfg, int first, int count, int at, int n, const real_t* values,
+                    const real_t* same, hipStream_t s);
+void launch_cfg_latch(real_t* cfg, int B, hipStream_t s);
 void launch_linearise_free(long n, const real_t* x, const real_t* u, const real_t* xnext,
                            const real_t* wind, const Bounds& bnd, real_t* jac, real_t* res,
                            hipStream_t s);

@@ -85,6 +85,18 @@ constexpr int kSolveRangeAll = 2 * kSolveListBuckets;
 constexpr int kSolveRangeLong = kSolveRangeAll + 2;
 constexpr int kSolveRangeShort = kSolveRangeAll + 4;
 
+// Per-instance weights and control bounds (BatchView::cfg), one record of
+// kCfgStride values per instance.  The first half is what the setters write; the
+// second half is what nmpc_batch_init latches from it, as the reference copies
+// weights and bounds into its QP at nmpc_init (ccs-c66x/cnmpc.c:899-931): the
+// stage Hessians as the solver sees them (a weight block within 1e-15 of the
+// identity counts as exact ones, qpDUNES/utils.c:106-117) and the bounds of that
+// moment.  The live bounds are what every later linearisation and feedback step
+// read (cnmpc.c:643-645, 1053-1062, 675-702).
+constexpr int kCfgStride = 72;
+constexpr int kCfgWq = 0, kCfgWr = 12, kCfgWt = 15, kCfgLb = 27, kCfgUb = 30;   // live
+constexpr int kCfgH = 36, kCfgHt = 51, kCfgLb0 = 63, kCfgUb0 = 66;              // latched by init
+
 struct BatchView {
     int B, N;
     int b0, nb;         // instance range [b0, b0 + nb) the QP kernels of one launch cover
@@ -132,6 +144,9 @@ struct BatchView {
     real_t H[15];       // regular-stage Hessian diagonal as the solver sees it
     real_t Ht[12];      // terminal-stage Hessian diagonal
     real_t lb[3], ub[3];
+    // Null while every instance has the weights and bounds above; otherwise
+    // [B][kCfgStride] records that take their place, instance by instance.
+    const real_t* cfg;
 };
 
 }  // namespace nmpc

@@ -36,6 +36,16 @@ constexpr real_t kLsMaxStep = (real_t)1.;
 // unit roundoff of real_t
 constexpr double kUnitRoundoff = sizeof(real_t) == 8 ? 1.1102230246251565e-16 : 5.9604644775390625e-8;
 
+// The stage-QP kernels exist twice: for batches whose instances all have the
+// batch's weights and bounds (kernel arguments), and, compiled with
+// -DNMPC_OWN_CFG=1, for batches with a record per instance (BatchView::cfg); the
+// choice is made at compile time so that the first form carries no trace of the
+// second.
+#ifndef NMPC_OWN_CFG
+#define NMPC_OWN_CFG 0
+#endif
+constexpr bool kOwnCfg = NMPC_OWN_CFG != 0;
+
 constexpr int kWave = 64;
 constexpr int kWabsStride = 16;      // BatchView::wabs: 15 stage variables, then the stage's pStep
 
@@ -61,6 +71,7 @@ struct Inst {
     real_t* wabs;
     int8_t *ieq, *prev, *chg;
     Scalars* sc;
+    const real_t* cfg;      // kOwnCfg: the instance's own weights and bounds (BatchView::cfg)
 };
 
 NMPC_DEV Inst instance(const BatchView& v, int b) {
@@ -91,6 +102,7 @@ NMPC_DEV Inst instance(const BatchView& v, int b) {
     I.prev = v.prev + sb * N1 * NZ;
     I.chg = v.chg + sb * N1;
     I.sc = v.sc + sb;
+    I.cfg = kOwnCfg ? v.cfg + sb * kCfgStride : nullptr;
     return I;
 }
 
@@ -105,6 +117,19 @@ NMPC_DEV int launch_instance(const BatchView& v, int i) {
 
 NMPC_DEV const real_t* stage_hessian(const BatchView& v, int k) {
     return k < v.N ? v.H : v.Ht;
+}
+// Entry j of the diagonal of stage k's Hessian.
+NMPC_DEV real_t hessian_entry(const BatchView& v, const Inst& I, int k, int j) {
+    if constexpr (kOwnCfg) return I.cfg[(k < v.N ? kCfgH : kCfgHt) + j];
+    else return k < v.N ? v.H[j] : v.Ht[j];
+}
+NMPC_DEV real_t lower_control_bound(const BatchView& v, const Inst& I, int i) {
+    if constexpr (kOwnCfg) return I.cfg[kCfgLb + i];
+    else return v.lb[i];
+}
+NMPC_DEV real_t upper_control_bound(const BatchView& v, const Inst& I, int i) {
+    if constexpr (kOwnCfg) return I.cfg[kCfgUb + i];
+    else return v.ub[i];
 }
 
 NMPC_DEV int wave_max(int x) {

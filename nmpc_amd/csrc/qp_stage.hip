@@ -39,7 +39,17 @@
 
 #pragma clang fp contract(off)
 
+// This file is compiled twice (qp_common.hpp, kOwnCfg); the two sets of kernels
+// and launchers live in two inline namespaces, and the launchers the library
+// calls (kernels.hpp) pick between them at the end of the first compilation.
+#if NMPC_OWN_CFG
+#define NMPC_CFG_NS perinstance
+#else
+#define NMPC_CFG_NS batchwide
+#endif
+
 namespace nmpc {
+inline namespace NMPC_CFG_NS {
 
 namespace {
 
@@ -262,10 +272,12 @@ NMPC_DEV real_t stage_pass(const BatchView& v, const Inst& I, real_t a, const St
         if (MODE != kTrialPoint) {
             for (int s = c0 + tid; s < c1; s += kStageThreads) {
                 const int nV = s < N ? NZ : NX;
-                const real_t* H = s < N ? v.H : v.Ht;
                 const real_t pt = I.p[s] + a * I.pStep[s];
                 if (MODE != kTrialValue) I.p[s] = pt;
-                L.vals[s] = stage_value(H, L.z + (s - c0) * NZ, L.q + (s - c0) * NZ, pt, nV);
+                if constexpr (kOwnCfg)
+                    L.vals[s] = stage_value(I.cfg + (s < N ? kCfgH : kCfgHt), L.z + (s - c0) * NZ, L.q + (s - c0) * NZ, pt, nV);
+                else
+                    L.vals[s] = stage_value(s < N ? v.H : v.Ht, L.z + (s - c0) * NZ, L.q + (s - c0) * NZ, pt, nV);
             }
         }
         __syncthreads();
@@ -379,7 +391,6 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
         while (kn < N && !needed(kn)) kn += WAVES;
         if (kn < N) fetch(kn, nxt);
         const bool ck = I.chg[k] != 0;
-        const real_t* Hn = stage_hessian(v, k + 1);
         // free columns of stage k; fixed states of stage k+1
         const bool fr = lane < NZ && cur.y[0] <= kEqTol && cur.y[1] <= kEqTol;
         const bool fx = lane < NX && (cur.y[2] >= kEqTol || cur.y[3] >= kEqTol);
@@ -392,7 +403,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
             if (e < NX * NZ) {
                 const int l = e % NZ;
                 Cs[e] = cur.c[t];
-                Zs[e] = cur.c[t] / v.H[l];
+                Zs[e] = cur.c[t] / hessian_entry(v, I, 0, l);
             }
         }
         real_t* zs = Cs + NX * NZ;                      // free until the finished row is put together
@@ -419,7 +430,7 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
 #pragma unroll
             for (int t = 0; t < 3; t++) {
                 if (i == j0 + t) {
-                    m[t] = 1. / Hn[i];
+                    m[t] = 1. / hessian_entry(v, I, k + 1, i);
                     if ((fixMask >> i) & 1ull) m[t] = 0.;
                 }
             }
@@ -684,7 +695,7 @@ NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I
             }
             I.qStep[e] = qs;
             if (I.wabs) I.wabs[s * kWabsStride + j] = qa;
-            const real_t d = qs / (k < N ? v.H[j] : v.Ht[j]);
+            const real_t d = qs / hessian_entry(v, I, k, j);
             const real_t dzv = -d;
             I.dz[e] = dzv;
             const pair_a yy = *(const pair_a*)(I.y + 2 * e);
@@ -717,9 +728,11 @@ NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I
             I.pStep[s] = ps;
             if (I.wabs) I.wabs[s * kWabsStride + NZ] = pa;
             const int nV = k < N ? NZ : NX;
-            const real_t* H = k < N ? v.H : v.Ht;
             const real_t pt = I.p[s] + a * ps;
-            L.vals[k] = stage_value(H, L.z + (k - c0) * NZ, L.q + (k - c0) * NZ, pt, nV);
+            if constexpr (kOwnCfg)
+                L.vals[k] = stage_value(I.cfg + (k < N ? kCfgH : kCfgHt), L.z + (k - c0) * NZ, L.q + (k - c0) * NZ, pt, nV);
+            else
+                L.vals[k] = stage_value(k < N ? v.H : v.Ht, L.z + (k - c0) * NZ, L.q + (k - c0) * NZ, pt, nV);
         }
         if (rows) {
             // gradient rows of the stages whose successor is in LDS now
@@ -806,8 +819,8 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
 #pragma unroll
         for (int i = 0; i < NU; i++) {
             const real_t ur = I.uref[s0 * NU + i];
-            I.zLow[s0 * NZ + NX + i] = v.lb[i] - ur;
-            I.zUpp[s0 * NZ + NX + i] = v.ub[i] - ur;
+            I.zLow[s0 * NZ + NX + i] = lower_control_bound(v, I, i) - ur;
+            I.zUpp[s0 * NZ + NX + i] = upper_control_bound(v, I, i) - ur;
         }
     }
     __syncthreads();
@@ -1494,16 +1507,16 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_hessian(BatchView 
     }
 }
 
-void launch_qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
+void qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
     hipLaunchKernelGGL(k_qp_begin, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
 }
-void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
+void newton_step(const BatchView& v, int next_it, hipStream_t s) {
     hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), step_lds_bytes(v.N), s, v, next_it);
 }
-bool line_search_tail_enabled(const BatchView& v) {
+bool tail_enabled(const BatchView& v) {
     return v.tailList != nullptr && v.wabs != nullptr && v.N <= kFastHorizonLarge;
 }
-void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
+void line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     const dim3 grid_fast((v.nb + 3) / 4);
     if (kFirstAttempt) {
         if (v.N <= kFastHorizonSmall)
@@ -1538,5 +1551,28 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
         hipLaunchKernelGGL(k_line_search_hessian, dim3(grid_hessian), dim3(kTailThreads),
                            (kTailThreads / kWave) * kSliceDoubles * sizeof(real_t), s, v, next_it);
 }
+
+}  // inline namespace
+
+#if !NMPC_OWN_CFG
+namespace perinstance {     // the second compilation of this file
+void qp_begin(const BatchView& v, const real_t* meas, hipStream_t s);
+void newton_step(const BatchView& v, int next_it, hipStream_t s);
+void line_search_tail(const BatchView& v, int next_it, hipStream_t s);
+}
+void launch_qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
+    if (v.cfg) perinstance::qp_begin(v, meas, s);
+    else batchwide::qp_begin(v, meas, s);
+}
+void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
+    if (v.cfg) perinstance::newton_step(v, next_it, s);
+    else batchwide::newton_step(v, next_it, s);
+}
+bool line_search_tail_enabled(const BatchView& v) { return batchwide::tail_enabled(v); }
+void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
+    if (v.cfg) perinstance::line_search_tail(v, next_it, s);
+    else batchwide::line_search_tail(v, next_it, s);
+}
+#endif
 
 }  // namespace nmpc

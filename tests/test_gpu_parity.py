@@ -380,6 +380,101 @@ def test_second_initialisation_keeps_solver_state(copies, watch):
     ctrl.close()
 
 
+def test_weights_and_bounds_per_instance(port_built):
+    """Instances of one batch with different weights and control bounds
+    (nmpc_batch_set_instance_weights / _control_bounds; the reference keeps them
+    per controller, ccs-c66x/cnmpc.c:988-1020): every instance against a port
+    controller configured the same way and taken through the same calls --
+    weights latched by the initialisation, bounds read by it, by every later
+    linearisation and by every feedback step, a batch-wide setter writing every
+    instance again.  Two weight sets and three bound sets; inputs from host and
+    from device memory."""
+    import torch
+    import portdriver as P
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+    N, B, steps = 30, 7, 5
+    d = S.make_batch(B, N, extra_steps=steps, seed=606, turn_start=(0.1, 0.5))
+    base = S.setup_args()
+    w2 = dict(state_weights=[2, 2, 2, 1, 1, 1, 3, 3, 12, 0.5, 0.5, 8], control_weights=[0.2, 8e2, 9e2],
+              terminal_weights=[1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1])
+    ident = dict(state_weights=[1] * 12, control_weights=[1] * 3, terminal_weights=[1] * 12)
+    b2 = dict(upper_control_bound=[0.9, 0.95, 0.9], lower_control_bound=[0.1, 0.05, 0.1])
+    b3 = dict(upper_control_bound=[0.62, 0.55, 0.55], lower_control_bound=[0.4, 0.45, 0.45])
+    # configuration of every instance at the first initialisation
+    cfg = [dict(base) for _ in range(B)]
+    for i in (2, 3):
+        cfg[i].update(w2); cfg[i].update(b2)
+    cfg[4].update(b3)
+    cfg[5].update(ident)
+    cfg[6].update(w2)
+    arr = lambda key, idx: np.array([cfg[i][key] for i in idx], dtype=np.float64)
+
+    bt = Batch(B, N)
+    bt.setup(**base)
+    bt.setup_instances(2, state_weights=arr("state_weights", range(2, 7)),
+                       control_weights=arr("control_weights", range(2, 7)),
+                       terminal_weights=arr("terminal_weights", range(2, 7)))
+    dev = torch.device("cuda", 0)
+    bt.setup_instances(2, upper_control_bound=torch.from_numpy(arr("upper_control_bound", range(2, 5))).to(dev),
+                       lower_control_bound=torch.from_numpy(arr("lower_control_bound", range(2, 5))).to(dev))
+    ports = []
+    for i in range(B):
+        p = P.Port(N)
+        c = cfg[i]
+        p.setup(c["state_weights"], c["control_weights"], c["terminal_weights"],
+                c["upper_control_bound"], c["lower_control_bound"])
+        ports.append(p)
+
+    def load_and_run(first_step, nsteps, refs0):
+        bt.initialise_horizon()
+        bt.set_wind_velocity(d["wind"])
+        bt.set_reference(d["refs"][:, refs0:refs0 + N + 1])
+        for i, p in enumerate(ports):
+            p.init()
+            p.set_wind(d["wind"][i])
+            for j in range(N + 1):
+                p.set_reference(d["refs"][i, refs0 + j], j)
+        for i, p in enumerate(ports):
+            assert_same(bt.stages(i), p.stages(), "stage records after loading, instance %d" % i)
+        for k in range(first_step, first_step + nsteps):
+            if k == first_step + 1:
+                # bounds changed in the middle of the run: instance 1 alone, through the
+                # per-instance setter; they reach the stage linearised next and the next feedback step
+                bt.setup_instances(1, upper_control_bound=np.array([b3["upper_control_bound"]]),
+                                   lower_control_bound=np.array([b3["lower_control_bound"]]))
+                c = cfg[1]
+                c.update(b3)
+                ports[1].setup(c["state_weights"], c["control_weights"], c["terminal_weights"],
+                               c["upper_control_bound"], c["lower_control_bound"])
+            bt.solve(d["meas"][:, k])
+            u, st, it = bt.get_controls()
+            for i, p in enumerate(ports):
+                p.feedback(d["meas"][i, k])
+                eu, est = p.controls()
+                what = "instance %d step %d" % (i, k)
+                assert st[i] == est and it[i] == p.num_iter(), what
+                assert_same(u[i], eu, "controls, " + what)
+            bt.update_horizon(d["refs"][:, refs0 + N + 1 + k - first_step])
+            for i, p in enumerate(ports):
+                p.update_horizon(d["refs"][i, refs0 + N + 1 + k - first_step])
+        for i, p in enumerate(ports):
+            assert_same(bt.stages(i), p.stages(), "final stage records, instance %d" % i)
+            assert_same(bt.globals_(i), p.globals_(), "final solver state, instance %d" % i)
+        return u
+
+    u1 = load_and_run(0, 3, 0)
+    assert len({tuple(r) for r in u1}) == B            # the configurations do make a difference
+    # a batch-wide setter writes every instance; weights wait for the next initialisation
+    bt.setup(**dict(base, **w2))
+    for c, p in zip(cfg, ports):
+        c.update(base); c.update(w2)
+        p.setup(c["state_weights"], c["control_weights"], c["terminal_weights"],
+                c["upper_control_bound"], c["lower_control_bound"])
+    load_and_run(3, 2, 0)
+    bt.close()
+
+
 def test_closed_loop_with_device_plant(port_built):
     """Controllers and simulated vehicles both on the GPU: feedback on the plant
     state, one RK4 step of the plant under the returned controls and a wind
