@@ -196,15 +196,20 @@ int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t *b, const real_t *waypo
                                             uint32_t first, uint32_t count);
 
 /* nmpc_batch_set_reference_from_waypoints for callers that cannot allocate
- * device memory (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  No counterpart in the reference.  The interpolated
- * points pass between the kernels through a fixed array in the library's code
- * object instead of a buffer allocated on demand: instances x count must not
- * exceed NMPC_STATIC_SCRATCH_POINTS (NMPC_E_ARG otherwise), `waypoints` must be
- * device memory, and kernel timing is not applied to its launches.  The call
- * makes no hipMalloc / hipFree.  All batches on one GPU share the array: calls
- * whose work overlaps on one GPU (different streams) race; calls on one stream
- * do not.  Results are those of nmpc_batch_set_reference_from_waypoints. */
+ * device memory (tight serving loops, harnesses that forbid hipMalloc, code
+ * that records work for replay).  No counterpart in the reference.  The
+ * interpolated points pass between the kernels through a fixed array in the
+ * library's code object instead of a buffer allocated on demand: instances x
+ * count must not exceed NMPC_STATIC_SCRATCH_POINTS (NMPC_E_ARG otherwise),
+ * `waypoints` must be device memory, and kernel timing is not applied to its
+ * launches.  The call makes no hipMalloc / hipFree and creates no event (checked:
+ * free device memory unchanged over warmed-up calls).  All batches on one GPU
+ * share the array; the library orders their calls with one event per GPU, made
+ * by nmpc_batch_create: a call waits, on its own stream, until the call made
+ * before it on that GPU (from whichever batch and stream) has read its points.
+ * Calls made from several host threads at once are not ordered.  Not exercised
+ * under HIP stream capture.  Results are those of
+ * nmpc_batch_set_reference_from_waypoints. */
 #define NMPC_STATIC_SCRATCH_POINTS 65536u   /* 8 MiB per GPU */
 int nmpc_batch_set_reference_from_waypoints_noalloc(nmpc_batch_t *b, const real_t *waypoints,
                                                     uint32_t n_waypoints, real_t t0, real_t dt,

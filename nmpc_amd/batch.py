@@ -56,6 +56,8 @@ class Batch:
             C.c_void_p(stream) if stream else None))
         self.h = h
         self._own_stream = not stream
+        self._stream_ptr = stream
+        self._torch_stream = None       # the caller's stream as a torch object, made on first use
         self._keep = []
 
     def close(self):
@@ -79,12 +81,21 @@ class Batch:
         to Batch() to avoid the wait)."""
         a = _Arg(x, shape, self.dtype)
         if _is_torch(x):
+            import torch
             if self._own_stream:
-                import torch
                 torch.cuda.current_stream(x.device).synchronize()
-            if len(self._keep) >= 256:      # bounded keep-alive list
-                self.synchronize()
-            self._keep.append(a)
+                # the library's private stream is not torch's to know: the tensor is
+                # kept here until the next wait (a list of 256 forces one)
+                if len(self._keep) >= 256:
+                    self.synchronize()
+                self._keep.append(a)
+            else:
+                # a stream the caller gave: torch's allocator is told that the tensor is
+                # in use on it and frees the memory only behind the work queued there,
+                # with no wait and nothing kept here
+                if self._torch_stream is None:
+                    self._torch_stream = torch.cuda.ExternalStream(self._stream_ptr, device=x.device)
+                x.record_stream(self._torch_stream)
         return a
 
     # -- configuration -------------------------------------------------

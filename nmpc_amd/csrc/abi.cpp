@@ -78,6 +78,15 @@ struct Staging {        // grow-only device scratch for host-side inputs/outputs
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+// The entry point that allocates nothing (nmpc_batch_set_reference_from_waypoints_noalloc)
+// keeps its scratch in one fixed array per GPU, shared by the batches on that GPU
+// whatever their streams: a call records this event behind its last reader and
+// waits for it before its first writer, so that calls which follow each other in
+// host order do not overlap on the device.  Made by nmpc_batch_create (creating an
+// event is no business of a call that must allocate nothing).
+constexpr int kMaxDevices = 64;
+hipEvent_t g_scratch_free[kMaxDevices];
+
 // start may be the stop event of the launch before (owned == false): launches
 // queued back to back share the event between them.
 struct TimedLaunch { int kind; hipEvent_t start, stop; bool owned; };
@@ -276,6 +285,11 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
     if (device < 0 || device >= ndev)
         return fail(NMPC_E_ARG, "nmpc_batch_create: device %d not present (%d visible)", device, ndev);
     HIP_TRY(hipSetDevice(device));
+    if (device < kMaxDevices && !g_scratch_free[device] &&
+        hipEventCreateWithFlags(&g_scratch_free[device], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        g_scratch_free[device] = nullptr;   // the no-alloc entry point then reports it
+    }
     nmpc_batch* b = new nmpc_batch();
     b->device = device;
     if (stream) {
@@ -609,7 +623,6 @@ int nmpc_batch_set_reference_from_waypoints(nmpc_batch_t* b, const real_t* waypo
 // process ends and shared by all batches on that GPU.
 constexpr uint32_t kStaticPoints = NMPC_STATIC_SCRATCH_POINTS;
 static __device__ __align__(256) real_t scratch[(size_t)kStaticPoints * 16];
-constexpr int kMaxDevices = 64;
 static real_t* g_scratch_ptr[kMaxDevices];      // device address of `scratch`, per GPU
 
 // The array's name is only a handle on the host; its memory on the current
@@ -653,12 +666,18 @@ int nmpc_batch_set_reference_from_waypoints_noalloc(nmpc_batch_t* b, const real_
         explicit Untimed(nmpc_batch* bb) : b(bb) { b->untimed = true; }
         ~Untimed() { b->untimed = false; }
     } untimed(b);
+    hipEvent_t scratch_free = b->device < kMaxDevices ? g_scratch_free[b->device] : nullptr;
+    if (!scratch_free) return fail(NMPC_E_HIP, "no event to order the users of the fixed scratch with");
+    // the call before this one on this GPU, on whatever stream, has read its points
+    HIP_TRY(hipStreamWaitEvent(b->stream, scratch_free, 0));
     // every entry of the points the kernels below read is written first: nothing
     // of an earlier call's contents is looked at
     launch_refs_from_waypoints(b->v.B, (const real_t*)waypoints, (int)n_waypoints, t0, dt, (int)first,
                                (int)count, points_dev, b->stream);
     HIP_TRY(hipGetLastError());
-    return store_and_linearise(b, points_dev, first, count);
+    const int rc = store_and_linearise(b, points_dev, first, count);
+    HIP_TRY(hipEventRecord(scratch_free, b->stream));
+    return rc;
 }
 
 int nmpc_batch_set_rti(nmpc_batch_t* b, int enabled) {
@@ -765,18 +784,27 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
             TRY(timed(b, NMPC_K_OTHER, [&] { launch_list_solves(v, ++b->solve_lists, b->stream); }));
             HIP_TRY(hipEventRecord(b->fork_event, b->stream));
             HIP_TRY(hipStreamWaitEvent(b->side_stream, b->fork_event, 0));
-            TRY(newton_iteration(b, solve_list_view(v, b->solve_lists, 1), it, b->stream));
+            // Whatever fails from here on, the second stream is joined back before the
+            // call returns: nothing queued on it may outlive the order of the batch's stream.
+            const int rc_long = newton_iteration(b, solve_list_view(v, b->solve_lists, 1), it, b->stream);
+            int rc_short;
             {
                 // intervals timed on the other stream do not continue the ones of this stream
                 hipEvent_t kept = b->chain_event;
                 b->chain_launches = false;
-                const int rc = newton_iteration(b, solve_list_view(v, b->solve_lists, 2), it, b->side_stream);
+                rc_short = newton_iteration(b, solve_list_view(v, b->solve_lists, 2), it, b->side_stream);
                 b->chain_launches = true;
                 b->chain_event = kept;
-                TRY(rc);
             }
-            HIP_TRY(hipEventRecord(b->join_event, b->side_stream));
-            HIP_TRY(hipStreamWaitEvent(b->stream, b->join_event, 0));
+            const hipError_t e_rec = hipEventRecord(b->join_event, b->side_stream);
+            const hipError_t e_wait = e_rec == hipSuccess ? hipStreamWaitEvent(b->stream, b->join_event, 0) : e_rec;
+            if (e_wait != hipSuccess) {
+                // no event to order the streams with: wait for the second one here
+                (void)hipStreamSynchronize(b->side_stream);
+                return fail(NMPC_E_HIP, "joining the second stream failed: %s", hipGetErrorString(e_wait));
+            }
+            TRY(rc_long);
+            TRY(rc_short);
             b->chain_event = nullptr;
         } else if (newton_solve_two_waves(v)) {
             // a grid that fills the chip several times over: the solve takes the running

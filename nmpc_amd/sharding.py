@@ -59,7 +59,9 @@ def gather_results(controls, status, iterations, group=None, counts=None):
     if any(c != m for c in counts):
         full = torch.cat([full[r * m:r * m + c] for r, c in enumerate(counts)], dim=0)
     words = full.view(torch.int32)
-    return (full[:, 0:3].contiguous(), words[:, 6].contiguous(), words[:, 7].contiguous())
+    # (records are float64 whatever the library's precision: exact for float32 controls,
+    # which come back in the type they went in)
+    return (full[:, 0:3].to(controls.dtype).contiguous(), words[:, 6].contiguous(), words[:, 7].contiguous())
 
 
 class ResultGather:
@@ -110,6 +112,7 @@ class ResultGather:
         src = rec.cpu() if self.staged else rec
         self.work[i] = dist.all_gather_into_tensor(self.full[i], src, group=self.group, async_op=True)
         self.last = i
+        self.dtype = controls.dtype
 
     def finish(self):
         import torch
@@ -122,4 +125,4 @@ class ResultGather:
         if any(c != self.m for c in self.counts):
             full = torch.cat([full[r * self.m:r * self.m + c] for r, c in enumerate(self.counts)], dim=0)
         words = full.view(torch.int32)
-        return (full[:, 0:3].contiguous(), words[:, 6].contiguous(), words[:, 7].contiguous())
+        return (full[:, 0:3].to(self.dtype).contiguous(), words[:, 6].contiguous(), words[:, 7].contiguous())

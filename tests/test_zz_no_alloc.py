@@ -77,3 +77,53 @@ def test_no_alloc_entry_point_matches_the_allocating_one():
     bt.set_reference_from_waypoints_noalloc(wp, t0, dt, 0, 90)     # 63 000 points: accepted
     bt.synchronize()
     bt.close()
+
+
+def test_no_alloc_calls_of_two_batches_on_their_own_streams_and_free_memory():
+    """Two batches on one GPU, each on a stream of its own, share the fixed
+    scratch: calls that follow each other in host order must not overlap on the
+    device (the second would overwrite points the first has not stored yet).
+    And the property the entry point exists for: warmed-up calls, kernel timing
+    switched on, leave the free device memory exactly as it was."""
+    import torch
+    from helpers import assert_same
+    from nmpc_amd import synthetic as S
+    from nmpc_amd.batch import Batch
+
+    dev = torch.device("cuda:0")
+    dt, t0, N = 1.0 / 50.0, 0.0, 100
+    sizes = (600, 560)
+    wps = [torch.from_numpy(_waypoints(B, np.random.default_rng(50 + i))).to(dev) for i, B in enumerate(sizes)]
+    want = []
+    for B, wp in zip(sizes, wps):           # what each batch's stage records must hold, from the allocating call
+        bt = Batch(B, N)
+        bt.setup(**S.setup_args())
+        bt.initialise_horizon()
+        bt.set_reference_from_waypoints(wp, t0, dt)
+        want.append([bt.stages(b) for b in (0, B - 1)])
+        bt.close()
+    torch.cuda.synchronize(dev)
+    bts = []
+    for B in sizes:                          # private streams: nothing orders the two batches but the library
+        bt = Batch(B, N)
+        bt.setup(**S.setup_args())
+        bt.set_profiling(True)
+        bts.append(bt)
+    free = None
+    for rep in range(4):
+        for bt in bts:
+            bt.reset()
+            bt.initialise_horizon()
+        if rep == 2:                         # two warmed-up rounds lie behind; from here nothing may be allocated
+            for bt in bts:
+                bt.synchronize()
+            free = torch.cuda.mem_get_info(dev)[0]
+        for bt, wp in zip(bts, wps):         # back to back, no wait between them
+            bt.set_reference_from_waypoints_noalloc(wp, t0, dt)
+    for bt in bts:
+        bt.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free, "device memory was allocated by warmed-up calls"
+    for bt, B, exp in zip(bts, sizes, want):
+        for b, e in zip((0, B - 1), exp):
+            assert_same(bt.stages(b), e, "stage records of instance %d of the batch of %d" % (b, B))
+        bt.close()
