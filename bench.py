@@ -76,20 +76,20 @@ METRIC = "NMPC solves/sec (prep+feedback) at batch B, default horizon"
 #                 gradient (96 B) and read/write the step (3 x 96 B): 4032 B;
 #                 blocks that are refactorised add the reverse Cholesky of a
 #                 12x12 diagonal + 12x12 sub-diagonal block (4.2 kflop), read the
-#                 Newton Hessian's block row (2304 B) instead of the factor's on
-#                 the way down and store the factor (1824 B): 2304 B more.  Every block is refactorised in
+#                 Newton Hessian's block row (the same 228 values) instead of the
+#                 factor's on the way down and store the factor: 1824 B more.  Every block is refactorised in
 #                 the first iteration; later iterations refactorise from the
 #                 last active-set change down, which is not counted here.
 #   newton_setup  per stage and iteration: gradient (0.38 kflop) + Hessian
 #                 blocks (4.7 kflop); reads C, c, z, y (1896 B), writes the
-#                 block row and gradient (2400 B)
+#                 block row (228 values) and gradient (1920 B)
 #   newton_step / qp_begin  per stage and call: stage update, clipping,
 #                 objective; reads C, c and the 15-vectors, writes them back
 ALGO = {
     "linearise": dict(flop=17000.0, bytes=1664.0),
     "newton_solve": dict(flop=840.0, bytes=4032.0),
-    "newton_factor": dict(flop=4200.0, bytes=2304.0),
-    "newton_setup": dict(flop=5080.0, bytes=4296.0),
+    "newton_factor": dict(flop=4200.0, bytes=1824.0),
+    "newton_setup": dict(flop=5080.0, bytes=3816.0),
     "newton_step": dict(flop=670.0, bytes=3100.0),
     "qp_begin": dict(flop=260.0, bytes=1100.0),
 }

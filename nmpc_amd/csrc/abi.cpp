@@ -326,7 +326,7 @@ int nmpc_batch_create(nmpc_batch_t** out, uint32_t instances, uint32_t horizon, 
         {(void**)&v.solveCount, 2 * kSolveListStride * sizeof(int)}, {(void**)&v.solveList, B * sizeof(int)},
         {(void**)&v.wabs, B * N1 * 16 * d},
         {(void**)&v.C, B * N * 180 * d},
-        {(void**)&v.hess, B * N * 288 * d}, {(void**)&v.chol, (B * N * kCholRow + kCholSlack) * d},
+        {(void**)&v.hess, (B * N * kCholRow + kCholSlack) * d}, {(void**)&v.chol, (B * N * kCholRow + kCholSlack) * d},
     };
     size_t total = 0;
     const size_t n_fields = sizeof fields / sizeof fields[0];
@@ -1010,9 +1010,12 @@ int nmpc_batch_get_global(nmpc_batch_t* b, uint32_t instance, real_t* o) {
     o += 12 * N;
     TRY(d2h(b, o, v.dl + ib * N * 12, 12 * N * d)); o += 12 * N;
     TRY(d2h(b, o, v.grad + ib * N * 12, 12 * N * d)); o += 12 * N;
-    TRY(d2h(b, o, v.hess + ib * N * 288, 288 * N * d)); o += 288 * N;
-    // the factor in the reference's [12][24] block rows (types.h:265-283)
-    std::vector<real_t> packed(kCholRow * N);
+    // Newton Hessian and factor in the reference's [12][24] block rows (types.h:265-283);
+    // the entries right of the diagonal, which the factorisation never reads, come out
+    // as zero (the reference computes them in the Hessian and leaves them zero in the factor)
+    std::vector<real_t> packedH(kCholRow * N), packed(kCholRow * N);
+    TRY(d2h(b, packedH.data(), v.hess + ib * N * kCholRow, kCholRow * N * d));
+    real_t* oh = o; o += 288 * N;
     TRY(d2h(b, packed.data(), v.chol + ib * N * kCholRow, kCholRow * N * d));
     real_t* of = o; o += 288 * N;
     std::vector<int8_t> ie(N1 * 15), pr(N1 * 15);
@@ -1038,6 +1041,8 @@ int nmpc_batch_get_global(nmpc_batch_t* b, uint32_t instance, real_t* o) {
             for (size_t j = 0; j < 12; j++) {
                 of[k * 288 + l * 24 + j] = packed[k * kCholRow + 12 * l + j];
                 of[k * 288 + l * 24 + 12 + j] = j <= l ? packed[k * kCholRow + kCholDiagRow[l] + j] : (real_t)0;
+                oh[k * 288 + l * 24 + j] = packedH[k * kCholRow + 12 * l + j];
+                oh[k * 288 + l * 24 + 12 + j] = j <= l ? packedH[k * kCholRow + kCholDiagRow[l] + j] : (real_t)0;
             }
     for (size_t k = 0; k < N1; k++)
         for (size_t i = 0; i < 15; i++) {

@@ -76,6 +76,10 @@ constexpr int kCholDiagRow[12] = {144 + 82, 144 + 70, 144 + 78, 144 + 44, 144 + 
 // Reads of a row's first twelve values, whatever its length, stay inside the
 // field: its allocation ends with this many spare values.
 constexpr int kCholSlack = 16;
+// The Newton Hessian's block rows (hess) have the same layout: the factorisation
+// reads the sub-diagonal block and the entries (i, j <= i) of the diagonal block
+// (dual_qp.c:835, 871, 892), so the entries right of the diagonal, which the
+// reference computes and never looks at, are neither computed nor stored.
 
 constexpr int kSolveListBuckets = 128;
 constexpr int kSolveListStride = 2 * kSolveListBuckets + 16;
@@ -121,7 +125,7 @@ struct BatchView {
     real_t* lam;        // [B][N][12]     lambda ring
     real_t* dl;         // [B][N][12]
     real_t* grad;       // [B][N][12]
-    real_t* hess;       // [B][N][12][24] "[L D]" block rows (types.h:265-283)
+    real_t* hess;       // [B][N][kCholRow] (+ kCholSlack): block rows of the Newton Hessian, laid out as the factor's
     real_t* chol;       // [B][N][kCholRow] (+ kCholSlack)
     int8_t* ieq;        // [B][N+1][15]
     int8_t* prev;       // [B][N+1][15]

@@ -96,7 +96,7 @@ NMPC_DEV Inst instance(const BatchView& v, int b) {
     I.lam = v.lam + sb * N * NX;
     I.dl = v.dl + sb * N * NX;
     I.grad = v.grad + sb * N * NX;
-    I.hess = v.hess + sb * N * 2 * NX * NX;
+    I.hess = v.hess + sb * N * kCholRow;
     I.chol = v.chol + sb * N * kCholRow;
     I.ieq = v.ieq + sb * N1 * NZ;
     I.prev = v.prev + sb * N1 * NZ;
@@ -113,6 +113,15 @@ NMPC_DEV int launch_instance(const BatchView& v, int i) {
         return at < v.listRange[1] ? v.list[at] : -1;
     }
     return i < v.nb ? v.b0 + i : -1;
+}
+
+// Where row l of a diagonal block starts in a block row of the Newton Hessian or of
+// its factor (kCholDiagRow), l known only at run time.
+NMPC_DEV int chol_diag_row(int l) {
+    int at = kCholDiagRow[0];
+#pragma unroll
+    for (int i = 1; i < NX; i++) at = (l == i) ? kCholDiagRow[i] : at;
+    return at;
 }
 
 NMPC_DEV const real_t* stage_hessian(const BatchView& v, int k) {

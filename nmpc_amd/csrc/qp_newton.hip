@@ -18,7 +18,6 @@ namespace nmpc {
 
 namespace {
 
-#define HS(M, k, l, i, j) (M)[(size_t)(k) * 2 * NX * NX + (i) * 2 * NX + (1 + (l)) * NX + (j)]
 
 // ------------------------------------------------------------------------
 // k_newton_solve works in 16-lane groups, four controller instances per
@@ -240,13 +239,6 @@ NMPC_DEV void fetch_rows_to_lds(const real_t* g0, lds_bytes image, std::integer_
      ...);
 }
 
-// Where row l of the factor's diagonal block starts in a block row, l known only at run time.
-NMPC_DEV int chol_diag_row(int l) {
-    int at = kCholDiagRow[0];
-#pragma unroll
-    for (int i = 1; i < NX; i++) at = (l == i) ? kCholDiagRow[i] : at;
-    return at;
-}
 constexpr int kCholPieces = (kCholRow + 2 * NX - 1) / (2 * NX);     // LDS-DMA pieces of 24 values
 
 // Entry t of a 12-vector held in registers, t known only at run time.
@@ -311,24 +303,16 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
     const int diagAt = chol_diag_row(tc) + tc;
     auto fetch_block_row = [&](bool fromH, int kk) {
         if constexpr (STAGED) {
-            if (fromH) {
-                const real_t* g0 = I.hess + (size_t)kk * (2 * NX * NX) + 2 * tc;
-                if (active && col) fetch_rows_to_lds(g0, image, Seq12{});
-            } else {
-                const real_t* g0 = I.chol + (size_t)kk * kCholRow + 2 * tc;
-                if (active && col)
-                    fetch_rows_to_lds(g0, image, std::make_integer_sequence<int, kCholPieces>{});
-            }
+            const real_t* g0 = (fromH ? I.hess : I.chol) + (size_t)kk * kCholRow + 2 * tc;
+            if (active && col) fetch_rows_to_lds(g0, image, std::make_integer_sequence<int, kCholPieces>{});
             if (active) ng = I.grad[kk * NX + tc];
         } else if (active) {
-            // one load per value, its place chosen between the two layouts (a choice
-            // between two loaded values would fetch both)
-            const real_t* row = (fromH ? I.hess + (size_t)kk * (2 * NX * NX)
-                                       : I.chol + (size_t)kk * kCholRow) + tc;
+            // the Newton Hessian and the factor have one layout: one load per value
+            const real_t* row = (fromH ? I.hess : I.chol) + (size_t)kk * kCholRow + tc;
 #pragma unroll
             for (int l = 0; l < NX; l++) {
-                nL[l] = row[fromH ? l * 2 * NX + NX : kCholDiagRow[l]];
-                nLs[l] = row[fromH ? l * 2 * NX : NX * l];
+                nL[l] = row[kCholDiagRow[l]];
+                nLs[l] = row[NX * l];
             }
             if (!fromH) nd = I.chol[(size_t)kk * kCholRow + diagAt];
             ng = I.grad[kk * NX + tc];
@@ -345,14 +329,12 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
         if constexpr (STAGED) {
             // the block row fetched during the last iteration has landed ...
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // value o of a factor block row sits in piece o / 24 at o % 24; one read
-            // per value, its place chosen between the two layouts
+            // value o of a block row sits in piece o / 24 at o % 24
             const real_t* mine = rows + slot + tc;
 #pragma unroll
             for (int l = 0; l < NX; l++) {
-                Ls[l] = mine[fromHess ? l * 128 : (l / 2) * 128 + (l % 2) * NX];
-                L[l] = mine[fromHess ? l * 128 + NX
-                                     : (kCholDiagRow[l] / (2 * NX)) * 128 + kCholDiagRow[l] % (2 * NX)];
+                Ls[l] = mine[(l / 2) * 128 + (l % 2) * NX];
+                L[l] = mine[(kCholDiagRow[l] / (2 * NX)) * 128 + kCholDiagRow[l] % (2 * NX)];
             }
             // ... and is in registers before the next one overwrites the image
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -382,8 +364,8 @@ NMPC_DEV int backward_pass(const BatchView& v, const Inst& I, int start, bool ac
                 if (active) {
 #pragma unroll
                     for (int l = 0; l < NX; l++) {
-                        L[l] = HS(I.hess, k, 0, l, tc);
-                        Ls[l] = HS(I.hess, k, -1, l, tc);
+                        L[l] = I.hess[(size_t)k * kCholRow + kCholDiagRow[l] + tc];
+                        Ls[l] = I.hess[(size_t)k * kCholRow + NX * l + tc];
                     }
                 }
                 failCol = -1;
@@ -591,12 +573,11 @@ NMPC_DEV void factor_sweep(Shared& sh, const BatchView& v, const Inst& I, int st
     for (int j = 0; j < NX; j++) { Ln[j] = 0.; nL[j] = 0.; nLs[j] = 0.; }
     auto fetch_block_row = [&](bool fromH, int kk) {
         if (!active) return;
-        // one load per value, its place chosen between the two layouts
-        const real_t* row = (fromH ? I.hess + (size_t)kk * (2 * NX * NX) : I.chol + (size_t)kk * kCholRow) + tc;
+        const real_t* row = (fromH ? I.hess : I.chol) + (size_t)kk * kCholRow + tc;
 #pragma unroll
         for (int l = 0; l < NX; l++) {
-            nL[l] = row[fromH ? l * 2 * NX + NX : kCholDiagRow[l]];
-            nLs[l] = row[fromH ? l * 2 * NX : NX * l];
+            nL[l] = row[kCholDiagRow[l]];
+            nLs[l] = row[NX * l];
         }
     };
     bool nextFromHess = __any(active && N - 1 <= start);
@@ -789,7 +770,7 @@ void k_newton_solve(BatchView v, int teamBeside) {
             const bool needReg = live && (st == ST_DIV_ZERO || minDiag < kDiagRegTol);
             if (!__any(needReg)) break;
             if (needReg && t < NX)
-                for (int k = 0; k < N; k++) HS(I.hess, k, 0, t, t) += kRegParam;
+                for (int k = 0; k < N; k++) I.hess[(size_t)k * kCholRow + chol_diag_row(t) + t] += kRegParam;
             if (needReg && t == 0) I.sc->regularized = 1;
             sweep = needReg;
             from = N - 1;
@@ -856,7 +837,7 @@ void k_newton_solve_team(BatchView v) {
     const bool needReg = live && (st == ST_DIV_ZERO || minDiag < kDiagRegTol);
     if (__any(needReg)) {
         if (needReg && t < NX)
-            for (int k = 0; k < N; k++) HS(I.hess, k, 0, t, t) += kRegParam;
+            for (int k = 0; k < N; k++) I.hess[(size_t)k * kCholRow + chol_diag_row(t) + t] += kRegParam;
         if (needReg && t == 0) I.sc->regularized = 1;
         real_t unused = kInfty;
         st = backward_pass<false>(v, I, N - 1, needReg, t, unused);

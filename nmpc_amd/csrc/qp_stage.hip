@@ -314,8 +314,9 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
 // Dual gradient and its norm (convergence test), then the Newton Hessian block
 // rows of every stage whose active set changed (dual_qp.c:423-597).  Each of
 // the four wavefronts assembles every fourth block row: it stages C_k and
-// C_k P_k in its own slice of LDS, 48 lanes then own three entries of the
-// 12x12 diagonal block each and add the free columns' dyads in column order.
+// C_k P_k in its own slice of LDS, 42 lanes then own two entries each of the
+// lower triangle of the 12x12 diagonal block and add the free columns' dyads in
+// column order.
 // gradKept: grad already holds the gradient at z (a slope trial at the committed
 // step stored it).
 // Returns false when the gradient norm passes the convergence test.
@@ -350,6 +351,7 @@ NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& 
 // C_k P_k, then C_k, whose place (and 108 entries more) the finished block row
 // takes before it leaves.
 constexpr int kSliceDoubles = NX * NZ + 2 * NX * NX;
+constexpr int kDiagPairs = 42;      // pairs (i, j), (i, j + 1), j even, j <= i < 12
 static_assert((kStageThreads / kWave) * kSliceDoubles <= kBufDoubles, "slices live in buf");
 // WITH_GRADIENT: every block row is assembled (the caller has marked every
 // stage changed), and the twelve rows of the dual gradient that belong to a
@@ -382,6 +384,17 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
         f.y[0] = yk.x; f.y[1] = yk.y;
         f.y[2] = yn.x; f.y[3] = yn.y;
     };
+    // lane p < kDiagPairs: entries (di, dj) and (di, dj + 1) of the diagonal block,
+    // dj even, the rows in order; dAt: where the pair sits in the block row
+    int di = 0, dj = lane;
+#pragma unroll
+    for (int r = 0; r < NX - 1; r++) {
+        const int pairs = di / 2 + 1;           // of row di
+        if (dj >= pairs) { dj -= pairs; di++; }
+    }
+    dj *= 2;
+    if (lane >= kDiagPairs) { di = 0; dj = 0; }
+    const int dAt = chol_diag_row(di) + dj;
     int k = w;
     while (k < N && !needed(k)) k += WAVES;
     Fetched cur{}, nxt{};
@@ -422,31 +435,28 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
             a -= zn;
             I.grad[k * NX + lane] = a;
         }
-        // diagonal block: E P_{k+1} E' + C_k P_k C_k'
+        // diagonal block: E P_{k+1} E' + C_k P_k C_k', the entries (i, j <= i) the
+        // factorisation reads (dual_qp.c:835, 871), two of a row per lane
         const bool wholeRow = k >= 1 && ck;             // the sub-diagonal block is written too
-        const int i = lane >> 2, j0 = (lane & 3) * 3;   // lanes 0..47: entries (i, j0..j0+2)
-        real_t m[3] = {0., 0., 0.};
-        if (lane < 48) {
+        real_t m[2] = {0., 0.};
+        if (lane < kDiagPairs) {
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
-                if (i == j0 + t) {
-                    m[t] = 1. / hessian_entry(v, I, k + 1, i);
-                    if ((fixMask >> i) & 1ull) m[t] = 0.;
+            for (int t = 0; t < 2; t++) {
+                if (di == dj + t) {
+                    m[t] = 1. / hessian_entry(v, I, k + 1, di);
+                    if ((fixMask >> di) & 1ull) m[t] = 0.;
                 }
             }
             for (int l = 0; l < NZ; l++) {
                 if (!((freeMask >> l) & 1ull)) continue;
-                const real_t ci = Cs[i * NZ + l];
+                const real_t ci = Cs[di * NZ + l];
 #pragma unroll
-                for (int t = 0; t < 3; t++) m[t] += ci * Zs[(j0 + t) * NZ + l];
+                for (int t = 0; t < 2; t++) m[t] += ci * Zs[(dj + t) * NZ + l];
             }
         }
+        // (entry dj + 1 of a row of odd length is the padding behind it)
         if (!wholeRow) {
-            if (lane < 48) {
-                real_t* Hd = I.hess + (size_t)k * 2 * NX * NX + i * 2 * NX + NX + j0;
-#pragma unroll
-                for (int t = 0; t < 3; t++) Hd[t] = m[t];
-            }
+            if (lane < kDiagPairs) store_pair(I.hess + (size_t)k * kCholRow + dAt, m[0], m[1]);
         } else {
             // The block row leaves as whole 16-byte pieces of consecutive addresses:
             // it is put together where C_k was (a wavefront's LDS accesses are
@@ -454,29 +464,26 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             real_t* row = Cs;
-            if (lane < 48) {
-#pragma unroll
-                for (int t = 0; t < 3; t++) row[i * 2 * NX + NX + j0 + t] = m[t];
-            }
+            if (lane < kDiagPairs) store_pair(row + dAt, m[0], m[1]);
             // sub-diagonal block: -C_k[:, :12] P_k, the quotients staged above
 #pragma unroll
             for (int t = 0; t < 3; t++) {
                 const int e = lane + t * kWave;
                 const int si = e / NX, sj = e % NX;
                 if (e < NX * NX)
-                    row[si * 2 * NX + sj] = ((freeMask >> sj) & 1ull) ? -Zs[si * NZ + sj] : 0.;
+                    row[e] = ((freeMask >> sj) & 1ull) ? -Zs[si * NZ + sj] : 0.;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            pair_a* out = (pair_a*)(I.hess + (size_t)k * 2 * NX * NX);
+            pair_a* out = (pair_a*)(I.hess + (size_t)k * kCholRow);
             const pair_a* in = (const pair_a*)row;
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
+            for (int t = 0; t < 2; t++) {
                 const int e = lane + t * kWave;
-                // (0.9 GB per batch of 4096 that the Newton solve reads once: streamed past
+                // (0.75 GB per batch of 4096 that the Newton solve reads once: streamed past
                 // the caches, which the stage vectors need more)
-                if (e < NX * NX) __builtin_nontemporal_store(in[e], &out[e]);
+                if (e < kCholRow / 2) __builtin_nontemporal_store(in[e], &out[e]);
             }
         }
         // reads done before the next block row overwrites the slice

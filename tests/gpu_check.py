@@ -49,7 +49,8 @@ def compare_state(bt, inst, p, tag):
     sa, sb = bt.stages(inst), p.stages()
     for name, (o, l) in STAGE_FIELDS.items():
         ok &= report("%s stage.%s" % (tag, name), sa[:, o:o + l], sb[:, o:o + l])
-    ga, gb = bt.globals_(inst), p.globals_()
+    from helpers import read_by_solver
+    ga, gb = read_by_solver(bt.globals_(inst)), read_by_solver(p.globals_())
     gf, _ = global_fields(bt.N)
     for name, (o, l) in gf.items():
         ok &= report("%s global.%s" % (tag, name), ga[o:o + l], gb[o:o + l])

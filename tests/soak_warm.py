@@ -9,7 +9,7 @@ import portdriver as P
 from nmpc_amd import synthetic as S
 from nmpc_amd.batch import Batch
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import same_bits
+from helpers import read_by_solver, same_bits
 
 PREC = os.environ.get("SOAK_PRECISION", "double")     # float: with NMPC_AMD_LIB=.../libcnmpc_f32.so
 BOUNDS = os.environ.get("SOAK_TIGHT_BOUNDS")           # narrow control bounds: many active constraints
@@ -60,7 +60,7 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
             p.feedback(d["meas"][b, k]); u, st = p.controls(); out.append((u, st, p.num_iter()))
             p.update_horizon(d["refs"][b, N + 1 + k])
         if b < len(dumps):
-            out.append(int((~same_bits(dumps[b][0], p.stages())).sum() + (~same_bits(dumps[b][1], p.globals_())).sum()))
+            out.append(int((~same_bits(dumps[b][0], p.stages())).sum() + (~same_bits(read_by_solver(dumps[b][1]), read_by_solver(p.globals_()))).sum()))
         return out
     with ThreadPoolExecutor(16) as pool:
         exp = list(pool.map(one, range(B)))

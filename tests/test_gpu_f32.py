@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
-from helpers import SEQUENCES_F32, assert_same, same_bits, drive_gpu_batch, golden
+from helpers import SEQUENCES_F32, assert_same, assert_same_state, same_bits, drive_gpu_batch, golden
 from nmpc_amd import _lib
 from nmpc_amd.batch import Batch, linearise_samples, rk4_samples
 lib = _lib.load()
@@ -42,7 +42,7 @@ for name in SEQUENCES_F32:
     if dump:
         assert_same(out["loaded_Cc"][0], g["loaded_Cc"], name + " C,c after loading")
         assert_same(out["final_stages"][0], g["final_stages"], name + " final stage records")
-        assert_same(out["final_globals"][0], g["final_globals"], name + " final solver state")
+        assert_same_state(out["final_globals"][0], g["final_globals"], name + " final solver state")
 # the four turn sequences as one batch
 gs = [golden("seq_turn%%d_f32" %% b) for b in range(4)]
 out = drive_gpu_batch(gs)
@@ -111,7 +111,7 @@ for b in range(count):
     eu, es = p.controls()
     assert same_bits(u[b], eu).all() and st[b] == es and it[b] == p.num_iter(), b
     assert_same(bt.stages(b), p.stages(), "stage records, instance %%d" %% (first + b))
-    assert_same(bt.globals_(b), p.globals_(), "solver state, instance %%d" %% (first + b))
+    assert_same_state(bt.globals_(b), p.globals_(), "solver state, instance %%d" %% (first + b))
 bt.close()
 print("child ok")
 """

@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import SEQUENCES, assert_same, same_bits, config_of, drive_gpu_batch, golden
+from helpers import SEQUENCES, assert_same, assert_same_state, same_bits, config_of, drive_gpu_batch, golden
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,7 +67,7 @@ def test_sequence_golden(name):
     if dump:
         assert_same(out["loaded_Cc"][0], g["loaded_Cc"], name + " C,c after loading")
         assert_same(out["final_stages"][0], g["final_stages"], name + " final stage records")
-        assert_same(out["final_globals"][0], g["final_globals"], name + " final solver state")
+        assert_same_state(out["final_globals"][0], g["final_globals"], name + " final solver state")
 
 
 def test_turn_sequences_as_one_batch():
@@ -230,7 +230,7 @@ def test_small_and_odd_shapes(port_built):
             assert_same(out["iters"][b], exp["iters"], tag + "iterations")
             assert_same(out["u"][b], exp["u"], tag + "controls")
             assert_same(out["final_stages"][b], exp["final_stages"], tag + "stage records")
-            assert_same(out["final_globals"][b], exp["final_globals"], tag + "solver state")
+            assert_same_state(out["final_globals"][b], exp["final_globals"], tag + "solver state")
 
 
 def test_model_and_linearisation_on_hostile_inputs(port_built):
@@ -338,7 +338,7 @@ def test_piecewise_reference_loading_and_reset():
         for a, b, what in zip(o0, o1, ("controls", "status", "iterations")):
             assert_same(b, a, what)
         assert_same(s1, s0, "stage records")
-        assert_same(g1, g0, "solver state")
+        assert_same_state(g1, g0, "solver state")
         bt1.close()
     # a fresh init leaves zero Jacobians whatever was there before
     bt0.initialise_horizon()
@@ -460,7 +460,7 @@ def test_weights_and_bounds_per_instance(port_built):
                 p.update_horizon(d["refs"][i, refs0 + N + 1 + k - first_step])
         for i, p in enumerate(ports):
             assert_same(bt.stages(i), p.stages(), "final stage records, instance %d" % i)
-            assert_same(bt.globals_(i), p.globals_(), "final solver state, instance %d" % i)
+            assert_same_state(bt.globals_(i), p.globals_(), "final solver state, instance %d" % i)
         return u
 
     u1 = load_and_run(0, 3, 0)
@@ -573,7 +573,7 @@ def test_relinearise_matches_resetting_every_reference_point(port_built):
             assert got[k][2][b] == c.num_iter()
             c.update_horizon(d["refs"][b, N + 1 + k])
         assert_same(gs[b], c.stages(), "stage records, instance %d" % b)
-        assert_same(gg[b], c.globals_(), "solver state, instance %d" % b)
+        assert_same_state(gg[b], c.globals_(), "solver state, instance %d" % b)
 
 
 def _interpolate_like_the_harness(t, points):
@@ -650,7 +650,7 @@ def test_plain_division_path_of_the_factorisation():
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
-from helpers import assert_same, drive_gpu_batch, golden
+from helpers import assert_same, assert_same_state, drive_gpu_batch, golden
 from nmpc_amd import _lib
 assert _lib.LIB_PATH.endswith("libcnmpc_repeat.so")
 for name in ("seq_straight", "seq_regularised", "seq_linesearch", "seq_bound", "seq_turn0", "seq_n500_0"):
@@ -661,7 +661,7 @@ for name in ("seq_straight", "seq_regularised", "seq_linesearch", "seq_bound", "
     assert_same(out["iters"][0], g["iters"], name + " QP iterations")
     assert_same(out["u"][0], g["u"], name + " controls")
     if dump:
-        assert_same(out["final_globals"][0], g["final_globals"], name + " final solver state")
+        assert_same_state(out["final_globals"][0], g["final_globals"], name + " final solver state")
 import portdriver as P
 from nmpc_amd import synthetic as S
 from nmpc_amd.batch import Batch

@@ -4,7 +4,7 @@ bounds changed between initialisation and reference loading."""
 import numpy as np
 import pytest
 
-from helpers import assert_same, same_bits
+from helpers import assert_same, assert_same_state, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -112,7 +112,7 @@ def batch_against_port(B, N, steps, seed, dumped, mutate=None):
             p.update_horizon(d["refs"][b, N + 1 + k])
         if b < dumped:
             assert_same(dumps[b][0], p.stages(), "stage records, instance %d" % b)
-            assert_same(dumps[b][1], p.globals_(), "solver state, instance %d" % b)
+            assert_same_state(dumps[b][1], p.globals_(), "solver state, instance %d" % b)
         return out
     with ThreadPoolExecutor(8) as pool:       # the port's calls release the interpreter lock
         exp = list(pool.map(one, range(B)))
