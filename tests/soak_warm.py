@@ -67,6 +67,22 @@ for B, N, steps, seed in zip(args[0::4], args[1::4], args[2::4], args[3::4]):
     bad = [(b, k) for b in range(B) for k in range(steps)
            if not (same_bits(got[k][0][b], exp[b][k][0]).all() and got[k][1][b] == exp[b][k][1]
                    and got[k][2][b] == exp[b][k][2])]
+    if os.environ.get("SOAK_TOLERANT"):
+        # a library whose arithmetic is not the reference's to the bit: solves whose status or
+        # iteration count differs, and the largest relative deviation of the controls of the others
+        differ = [(b, k) for b in range(B) for k in range(steps)
+                  if got[k][1][b] != exp[b][k][1] or got[k][2][b] != exp[b][k][2]]
+        skip = set(differ)
+        rel = 0.0
+        for b in range(B):
+            for k in range(steps):
+                if (b, k) not in skip and exp[b][k][1] == 0:
+                    e = np.asarray(exp[b][k][0], dtype=np.float64)
+                    rel = max(rel, float(np.max(np.abs(got[k][0][b] - e) / np.maximum(np.abs(e), 1e-300))))
+        inst = len({b for b, _ in differ})
+        print("tolerant: %d of %d solves (%d of %d instances) differ in status or iteration count; "
+              "largest relative control deviation of the others %.3e; bitwise different controls: %d"
+              % (len(differ), B * steps, inst, B, rel, len(bad)), flush=True)
     ok = sum(int((g[1] == 0).sum()) for g in got)
     dumped = [exp[b][steps] for b in range(len(dumps))]
     print(PREC, "rti" if RTI else "", "tight" if BOUNDS else "", "noise x%g" % NOISE if NOISE != 1 else "", "hostile %g" % HOSTILE if HOSTILE else "", "B %d N %d steps %d seed %d: %d mismatches, %d of %d solves converged" % (B, N, steps, seed, len(bad), ok, B * steps), bad[:5],
