@@ -417,13 +417,17 @@ __global__ __launch_bounds__(256, NMPC_LINEARISE_WAVES) void k_linearise(BatchVi
             up = (OWN ? L.own[g][NZ + NU + jv - NX] : L.ub[jv - NX]) - uj;
         }
         const size_t e = zrow + jv;
-        // (a cold solve writes 0.3 GB of these before anything reads them)
-        __builtin_nontemporal_store(qs, &v.qStep[e]);
-        __builtin_nontemporal_store(-d, &v.dz[e]);
-        __builtin_nontemporal_store((real_t)0.0, &v.zUnc[e]);
-        __builtin_nontemporal_store((real_t)0.0, &v.q[e]);
-        __builtin_nontemporal_store(lo, &v.zLow[e]);
-        __builtin_nontemporal_store(up, &v.zUpp[e]);
+// Plain stores: fifteen lanes write a stage's 120 bytes, the lanes of the next
+        // stage the 120 behind them, and the L2 puts the 32-byte sectors the two share
+        // together before they leave.  Streaming stores wrote each such sector twice
+        // (1.21 GB per launch of 409 600 stages against 0.95 GB now and 0.925 GB
+        // algorithmic, rocprofv3 --pmc WRITE_SIZE; the kernel's time is the same).
+        v.qStep[e] = qs;
+        v.dz[e] = -d;
+        v.zUnc[e] = (real_t)0.0;
+        v.q[e] = (real_t)0.0;
+        v.zLow[e] = lo;
+        v.zUpp[e] = up;
     };
     if (active && c > 0) restage(c + 2, dot_own);
     if (active && c < 4) {          // the residual (c == 0) and the position columns against lambda_{k+1}
