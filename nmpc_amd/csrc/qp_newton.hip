@@ -503,11 +503,21 @@ constexpr int kMaxInstances = 4 * 512;      // two teams per CU; beyond, the one
 
 typedef int flags4 __attribute__((ext_vector_type(4)));
 
+// Top-down sweep: wave 1 fetches the rows of the blocks ahead and hands them over
+// through a ring of kRing slots, thirteen 16-byte words per lane: six pairs of the
+// lane's row of the diagonal block, six of the sub-diagonal block, {right-hand side, pivot}.
+constexpr int kRing = 4;
+constexpr int kRowWords = NX + 1;
+
 struct Shared {
     pair_a row[2][NX][kWave];       // by block parity: row l of the block row, {chol(k,0,l,t), chol(k,-1,l,t)} of the lane's column t
+    pair_a ring[kRing][kRowWords][kWave];
     real_t minDiag[kWave];
     // [0] blocks handed over by wave 0, [1] blocks taken by wave 1, [3] the sweep is given up
     __attribute__((aligned(16))) int count[4];
+    // top-down sweep: [0] blocks handed over by wave 1, [1] blocks taken by wave 0,
+    // [2] wave 0's word to wave 1 after the bottom-up sweeps: 1 feed the top-down sweep, 2 nothing to do
+    __attribute__((aligned(16))) int fed[4];
 #ifdef NMPC_SOLVE_STATS
     long long waited[kWaves], looked[kWaves];     // per wavefront: cycles and looks spent in waits
 #endif
@@ -546,6 +556,16 @@ NMPC_DEV void post(int* counter, int value) {
 // for ever: after kPatience looks (a tenth of a second, where the counter normally
 // is there at the first) the sweep is given up from here.
 constexpr int kPatience = 1 << 21;
+template <int WHICH>
+NMPC_DEV int await_fed(Shared& sh, int value) {     // -> the counter as seen (>= value), or -1 after kPatience looks
+    NMPC_WAIT_CLOCK(sh);
+    for (int looks = 0;;) {
+        NMPC_WAIT_LOOK();
+        const int f = peek(sh.fed)[WHICH];
+        if (f >= value) return f;
+        if (++looks >= kPatience) return -1;
+    }
+}
 template <int WHICH>
 NMPC_DEV bool await(Shared& sh, int value) {
     NMPC_WAIT_CLOCK(sh);
@@ -673,10 +693,109 @@ NMPC_DEV void substitution_sweep(Shared& sh, const BatchView& v, const Inst& I, 
     }
 }
 
+// Wave 1 during the top-down sweep: the rows of block k (forward_pass's fetch_row)
+// from global memory into slot k % kRing, two blocks in flight.
+NMPC_DEV void forward_feed(Shared& sh, const BatchView& v, const Inst& I, bool live, int lane) {
+    const int N = v.N;
+    const int t = lane & 15;
+    const int tc = t < NX ? t : 0;
+    const int diagRow = chol_diag_row(tc);
+    struct Row { pair_a w[kRowWords]; };
+    auto fetch = [&](int kk, Row& r) {
+        if (!live || kk >= N) return;
+        const real_t* row = I.chol + (size_t)kk * kCholRow;
+        const pair_a* pd = (const pair_a*)(row + diagRow);
+        const pair_a* pr = (const pair_a*)(row + NX * tc);
+#pragma unroll
+        for (int j = 0; j < NX / 2; j++) { r.w[j] = pd[j]; r.w[NX / 2 + j] = pr[j]; }
+        r.w[NX].x = I.tmp[kk * NX + tc];
+        r.w[NX].y = row[diagRow + tc];
+    };
+    auto hand_over = [&](int kk, const Row& r) -> bool {
+        if (kk >= N) return true;
+        if (kk >= kRing && await_fed<1>(sh, kk - kRing + 1) < 0) return false;     // the slot is free again
+#pragma unroll
+        for (int j = 0; j < kRowWords; j++) sh.ring[kk % kRing][j][lane] = r.w[j];
+        post(&sh.fed[0], kk + 1);
+        return true;
+    };
+    Row a, b;
+#pragma unroll
+    for (int j = 0; j < kRowWords; j++) { a.w[j].x = 0.; a.w[j].y = 0.; b.w[j] = a.w[j]; }
+    a.w[NX].y = 1.; b.w[NX].y = 1.;
+    fetch(0, a);
+    fetch(1, b);
+    for (int k = 0; k < N; k += 2) {
+        if (!hand_over(k, a)) return;
+        fetch(k + 2, a);
+        if (!hand_over(k + 1, b)) return;
+        fetch(k + 3, b);
+    }
+}
+
+// forward_pass with the rows coming out of the ring wave 1 fills.
+NMPC_DEV void forward_pass_fed(Shared& sh, const BatchView& v, const Inst& I, bool live, int t, int lane) {
+    const int N = v.N;
+    const bool col = t < NX;
+    real_t norm2 = 0.;
+    int seen = 0;                   // blocks known to be in the ring
+    bool lost = false;
+    auto fetch_row = [&](int kk, ForwardRow& r) {
+        if (seen < kk + 1) {
+            seen = await_fed<0>(sh, kk + 1);
+            if (seen < 0) { lost = true; return; }
+        }
+        const pair_a (&slot)[kRowWords][kWave] = sh.ring[kk % kRing];
+#pragma unroll
+        for (int j = 0; j < NX / 2; j++) {
+            const pair_a d = slot[j][lane], s = slot[NX / 2 + j][lane];
+            r.Ld[2 * j] = d.x; r.Ld[2 * j + 1] = d.y;
+            r.Lr[2 * j] = s.x; r.Lr[2 * j + 1] = s.y;
+        }
+        const pair_a e = slot[NX][lane];
+        r.sum = e.x;
+        r.d = e.y;
+        post(&sh.fed[1], kk + 1);
+    };
+    auto block = [&](int k, ForwardRow& cur, ForwardRow& nxt, const real_t (&xin)[NX], real_t (&xout)[NX]) {
+        if (k + 1 < N) fetch_row(k + 1, nxt);
+        real_t sum = cur.sum;
+        if (k > 0) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) sum -= cur.Lr[j] * xin[j];
+        }
+        real_t mine = 0.;
+        const Pivot pv{cur.d, 1.0 / cur.d};
+        if (__any(plain_division_needed(cur.d)))
+            forward_columns<false>(xout, mine, sum, cur.Ld, pv, t, Seq12{});
+        else
+            forward_columns<true>(xout, mine, sum, cur.Ld, pv, t, Seq12{});
+        if (live && col) I.dl[k * NX + t] = mine;
+#pragma unroll
+        for (int j = 0; j < NX; j++) norm2 += xout[j] * xout[j];
+    };
+    ForwardRow a, b;
+    real_t xa[NX], xb[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) { a.Ld[j] = 0.; a.Lr[j] = 0.; b.Ld[j] = 0.; b.Lr[j] = 0.; xa[j] = 0.; xb[j] = 0.; }
+    a.sum = b.sum = 0.;
+    a.d = b.d = 1.;
+    fetch_row(0, a);
+    for (int k = 0; k < N && !lost; k += 2) {
+        block(k, a, b, xb, xa);
+        if (k + 1 < N) block(k + 1, b, a, xa, xb);
+    }
+    if (lost) {                     // wave 1 did not deliver: the sweep again, on this wave's own
+        forward_pass(v, I, live, t);
+        return;
+    }
+    if (live && t == 0) I.sc->dlNorm2 = norm2;
+}
+
 // Returns true when the sweep was given up; minDiag as backward_pass leaves it.
 NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bool active, int role,
                     int lane, real_t& minDiag) {
-    if (threadIdx.x < 4) sh.count[threadIdx.x] = 0;
+    if (threadIdx.x < 4) { sh.count[threadIdx.x] = 0; sh.fed[threadIdx.x] = 0; }
 #ifdef NMPC_SOLVE_STATS
     if (threadIdx.x < kWaves) { sh.waited[threadIdx.x] = 0; sh.looked[threadIdx.x] = 0; }
 #endif
@@ -723,23 +842,12 @@ NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bo
 __device__ unsigned long long g_solve_stats[16];
 #endif
 
-// Does the team form (k_newton_solve_team, launched in front of this kernel) take a
-// listed launch?  Only a list short enough for one team per CU.
-NMPC_DEV bool team_takes_list(const BatchView& v) {
-#ifndef NMPC_SINGLE_PRECISION
-    return v.list && v.listRange[1] - v.listRange[0] <= team::kMaxInstances;
-#else
-    return false;
-#endif
-}
-
 template <int WAVES>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-void k_newton_solve(BatchView v, int teamBeside) {
+void k_newton_solve(BatchView v) {
 #ifdef NMPC_SOLVE_STATS
     const long long c0 = clock64();
 #endif
-    if (teamBeside && team_takes_list(v)) return;
     const int lane = threadIdx.x, g = lane >> 4, t = lane & 15;
     const int first = blockIdx.x * kGroupsPerWave;
     const int b0 = launch_instance(v, first);
@@ -800,20 +908,18 @@ void k_newton_solve(BatchView v, int teamBeside) {
 
 #ifndef NMPC_SINGLE_PRECISION
 // The same solve with the first bottom-up sweep run by a team of two wavefronts
-// (namespace team); regularised second sweeps, sweeps the team gives up, and the
-// top-down substitution are wave 0's alone, through the code of k_newton_solve.
-__global__ __launch_bounds__(team::kWaves * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_newton_solve_team(BatchView v) {
-    __shared__ team::Shared sh;
+// (namespace team); regularised second sweeps and sweeps the team gives up are
+// wave 0's alone, through the code of k_newton_solve; in the top-down
+// substitution wave 1 fetches the rows ahead of wave 0.  A workgroup takes
+// every gridDim.x-th set of four instances, so a grid of two teams per CU serves
+// a list of any length (only the device knows it).
+NMPC_DEV void team_solve(team::Shared& sh, const BatchView& v, int first, int role, int lane) {
 #ifdef NMPC_SOLVE_STATS
     const long long c0 = clock64();
 #endif
-    if (v.list && !team_takes_list(v)) return;      // k_newton_solve, launched behind, takes it
-    const int role = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1), g = lane >> 4, t = lane & 15;
-    const int first = blockIdx.x * kGroupsPerWave;
+    const int g = lane >> 4, t = lane & 15;
     const int b0 = launch_instance(v, first);
     if (b0 < 0) return;
-    if (role == 0) __builtin_amdgcn_s_setprio(3);
     const int bg = launch_instance(v, first + g);
     const bool have = bg >= 0;
     const int b = have ? bg : b0;
@@ -826,7 +932,11 @@ void k_newton_solve_team(BatchView v) {
 
     real_t minDiag = kInfty;
     const bool gaveUp = team::sweep(sh, v, I, start, live, role, lane, minDiag);
-    if (role != 0) return;
+    if (role != 0) {
+        // wave 0 decides what follows the bottom-up sweeps; then this wave feeds its top-down sweep
+        if (team::await_fed<2>(sh, 1) == 1) team::forward_feed(sh, v, I, live, lane);
+        return;
+    }
     int st = ST_OK;
     if (gaveUp) {
         minDiag = kInfty;
@@ -846,11 +956,16 @@ void k_newton_solve_team(BatchView v) {
             live = false;
         }
     }
-    if (!__any(live)) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // a second sweep's stores are done before wave 1 reads
+    if (!__any(live)) {
+        team::post(&sh.fed[2], 2);
+        return;
+    }
+    team::post(&sh.fed[2], 1);
 #ifdef NMPC_SOLVE_STATS
     const long long c1 = clock64();
 #endif
-    forward_pass(v, I, live, t);
+    team::forward_pass_fed(sh, v, I, live, t, lane);
 #ifdef NMPC_SOLVE_STATS
     const long long c2 = clock64();
     if (lane == 0) {
@@ -863,6 +978,18 @@ void k_newton_solve_team(BatchView v) {
         atomicMax(&g_solve_stats[part + 5], (unsigned long long)(c2 - c1));
     }
 #endif
+}
+
+__global__ __launch_bounds__(team::kWaves * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_newton_solve_team(BatchView v) {
+    __shared__ team::Shared sh;
+    const int role = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const int count = v.list ? v.listRange[1] - v.listRange[0] : v.nb;
+    if (role == 0) __builtin_amdgcn_s_setprio(3);
+    for (int first = blockIdx.x * kGroupsPerWave; first < count; first += gridDim.x * kGroupsPerWave) {
+        team_solve(sh, v, first, role, lane);
+        __syncthreads();            // both wavefronts are done with the counters before the next set resets them
+    }
 }
 #endif  // NMPC_SINGLE_PRECISION
 
@@ -959,9 +1086,12 @@ void launch_list_solves(const BatchView& v, unsigned epoch, hipStream_t s) {
     int* ctr = v.solveCount + (epoch & 1) * kSolveListStride;
     int* spare = v.solveCount + ((epoch + 1) & 1) * kSolveListStride;
     const unsigned blocks = (unsigned)((v.nb + kListThreads - 1) / kListThreads);
-    // long sweeps: those that start in the lower three quarters of the horizon's blocks
+    // long sweeps: those that start in the lower 85 % of the horizon's blocks (with the long
+    // part's solve run by teams the two parts of an iteration end together there: 5.16 ms per
+    // cold solve of 4 096 instances at 0.75, 5.14 at 0.85 and 0.92, 5.26 at 0.6)
     const int nBuckets = v.N < kSolveListBuckets ? v.N : kSolveListBuckets;
-    const int longBuckets = kSolveListBuckets - nBuckets + (3 * nBuckets + 3) / 4;
+    static const double longFrac = getenv("NMPC_LONG_FRAC") ? atof(getenv("NMPC_LONG_FRAC")) : 0.85;
+    const int longBuckets = kSolveListBuckets - nBuckets + (int)(longFrac * nBuckets + 0.75);
     hipLaunchKernelGGL(k_list_count, dim3(blocks), dim3(kListThreads), 0, s, v, ctr);
     hipLaunchKernelGGL(k_list_fill, dim3(blocks), dim3(kListThreads), 0, s, v, ctr, spare, longBuckets);
 }
@@ -980,9 +1110,11 @@ BatchView solve_list_view(const BatchView& v, unsigned epoch, int part) {
 }
 
 // The team form pays where it leaves no SIMD short of work: an unlisted launch of at
-// most two teams per CU, or the long-sweep part of a two-part iteration (whose
-// length only the device knows: both kernels are launched and the list's length
-// decides which of them works).  NMPC_NO_TEAM=1 keeps the one-wavefront form.
+// most two teams per CU, or the long-sweep part of a two-part iteration.  The
+// length of that part only the device knows; a grid of two teams per CU takes
+// whatever it is, in rounds if need be (with the bench workload's sixth of the
+// instances one round does up to 12 000 instances).  NMPC_NO_TEAM=1 keeps the
+// one-wavefront form.
 static bool team_wanted(const BatchView& v) {
 #ifdef NMPC_SINGLE_PRECISION
     return false;
@@ -996,17 +1128,15 @@ static bool team_wanted(const BatchView& v) {
 
 void launch_newton_solve(const BatchView& v, hipStream_t s) {
     const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
-    int teamBeside = 0;
 #ifndef NMPC_SINGLE_PRECISION
     if (team_wanted(v)) {
-        const unsigned teams = blocks < team::kMaxInstances / kGroupsPerWave ? blocks : team::kMaxInstances / kGroupsPerWave;
-        hipLaunchKernelGGL(k_newton_solve_team, dim3(teams), dim3(team::kWaves * kWave), 0, s, v);
-        if (!v.list) return;
-        teamBeside = 1;
+        const unsigned most = team::kMaxInstances / kGroupsPerWave;
+        hipLaunchKernelGGL(k_newton_solve_team, dim3(blocks < most ? blocks : most), dim3(team::kWaves * kWave), 0, s, v);
+        return;
     }
 #endif
-    if (newton_solve_two_waves(v)) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v, teamBeside);
-    else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v, teamBeside);
+    if (newton_solve_two_waves(v)) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
+    else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);
 }
 
 #ifdef NMPC_SOLVE_STATS

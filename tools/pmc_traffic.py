@@ -32,7 +32,7 @@ def collect(path, counter):
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            m = re.search(r"nmpc::(\w+)", row["Kernel_Name"])
+            m = re.search(r"nmpc::(?:\w+::)*(k_\w+)", row["Kernel_Name"])
             name = m.group(1) if m else row["Kernel_Name"].split("(")[0]
             per[name].append(float(row["Counter_Value"]))
     return per

@@ -55,7 +55,7 @@ out, tag = sys.argv[1], sys.argv[2]
 def mix(path):
     per = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(path)):
-        m = re.search(r"nmpc::(\w+)", r["Kernel_Name"])
+        m = re.search(r"nmpc::(?:\w+::)*(k_\w+)", r["Kernel_Name"])
         if m: per[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per.items()}
 res = {"source": "rocprofv3 --pmc, one pass per file, mean per launch; SQ instruction counters count wavefront instructions"}

@@ -14,7 +14,7 @@ f = glob.glob("$out/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
-    m = re.search(r"nmpc::(\w+)", n); return m.group(1) if m else n[:30]
+    m = re.search(r"nmpc::(?:\w+::)*(k_\w+)", n); return m.group(1) if m else n[:30]
 # last step only
 names = [short(r["Kernel_Name"]) for r in rows]
 idx = [i for i, n in enumerate(names) if n == "k_qp_begin"]
