@@ -562,7 +562,7 @@ NMPC_DEV int await_fed(Shared& sh, int value) {     // -> the counter as seen (>
     for (int looks = 0;;) {
         NMPC_WAIT_LOOK();
         const int f = peek(sh.fed)[WHICH];
-        if (f >= value) return f;
+        if (f >= value) { asm volatile("" ::: "memory"); return f; }
         if (++looks >= kPatience) return -1;
     }
 }
@@ -573,7 +573,7 @@ NMPC_DEV bool await(Shared& sh, int value) {
         NMPC_WAIT_LOOK();
         const flags4 f = peek(sh.count);
         if (f[3] != 0) return false;
-        if (f[WHICH] >= value) return true;
+        if (f[WHICH] >= value) { asm volatile("" ::: "memory"); return true; }
         if (++looks >= kPatience) {
             post(&sh.count[3], 2);
             return false;
