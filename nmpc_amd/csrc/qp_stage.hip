@@ -31,6 +31,7 @@
 // the workgroup.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <utility>
 
@@ -357,8 +358,11 @@ static_assert((kStageThreads / kWave) * kSliceDoubles <= kBufDoubles, "slices li
 // stage changed), and the twelve rows of the dual gradient that belong to a
 // block row (gradient_row's expression, term for term) are made from the
 // Jacobian while it is in LDS, which saves reading it a second time.
+// A workgroup that shares an instance with others takes the block rows first + w,
+// first + w + stride, ... (stride: the wavefronts of all of them).
 template <int WAVES, bool WITH_GRADIENT = false>
-NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices) {
+NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices, int first = 0,
+                               int stride = WAVES) {
     const int tid = threadIdx.x, N = v.N;
     const int w = tid >> 6, lane = tid & 63;
     real_t* Zs = slices + w * kSliceDoubles;
@@ -395,13 +399,13 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
     dj *= 2;
     if (lane >= kDiagPairs) { di = 0; dj = 0; }
     const int dAt = chol_diag_row(di) + dj;
-    int k = w;
-    while (k < N && !needed(k)) k += WAVES;
+    int k = first + w;
+    while (k < N && !needed(k)) k += stride;
     Fetched cur{}, nxt{};
     if (k < N) fetch(k, cur);
     while (k < N) {
-        int kn = k + WAVES;
-        while (kn < N && !needed(kn)) kn += WAVES;
+        int kn = k + stride;
+        while (kn < N && !needed(kn)) kn += stride;
         if (kn < N) fetch(kn, nxt);
         const bool ck = I.chg[k] != 0;
         // free columns of stage k; fixed states of stage k+1
@@ -862,7 +866,8 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
 }
 
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int nextIt) {
+// hessianApart: the Hessian block rows of the next set-up are left to k_step_hessian.
+__global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int nextIt, int hessianApart) {
     extern __shared__ real_t lds_raw[];
     const StageLds L = carve_step(lds_raw, v.N);
     const int b = launch_instance(v, blockIdx.x), tid = threadIdx.x;
@@ -983,8 +988,23 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
     }
     // grad can only be the first sweep's here when it belongs to the full step
     commit_step(v, I, L, alpha, lsIter, nextIt, (alpha == zAlpha) ? &objKept : nullptr,
-                alpha == gradAlpha, true,
+                alpha == gradAlpha, !hessianApart,
                 (haveSlope && gradFromSweep && alpha == 1.) ? &fullStepNorm2 : nullptr);
+}
+
+// Newton Hessian block rows after a k_newton_step that left them out, `parts`
+// workgroups per instance: in a launch of few instances, or of long horizons, an
+// instance's block rows are a latency chain for the four wavefronts of its step,
+// while most of the chip has nothing to do.  Instances whose search was handed
+// over get theirs from k_line_search_hessian, after their commit.
+__global__ __launch_bounds__(kStageThreads) void k_step_hessian(BatchView v, int parts) {
+    extern __shared__ real_t lds_raw[];
+    const int b = launch_instance(v, blockIdx.x / parts);
+    if (b < 0) return;
+    Inst I = instance(v, b);
+    if (I.sc->status != ST_RUNNING || I.sc->lsDeferred) return;
+    constexpr int kWaves = kStageThreads / kWave;
+    assemble_hessian<kWaves>(v, I, lds_raw, (blockIdx.x % parts) * kWaves, parts * kWaves);
 }
 
 // ------------------------------------------------------------------------
@@ -1518,7 +1538,18 @@ void qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
     hipLaunchKernelGGL(k_qp_begin, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
 }
 void newton_step(const BatchView& v, int next_it, hipStream_t s) {
-    hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), step_lds_bytes(v.N), s, v, next_it);
+    // Long horizons: 1 024 x 500 cold 16.38 -> 16.06 ms; at horizon 100 the second launch
+    // costs what it saves (4 096 x 100: 5.15 against 5.17 ms).  NMPC_HESSIAN_APART=0 / 1: never / always.
+    static const int forced = getenv("NMPC_HESSIAN_APART") ? atoi(getenv("NMPC_HESSIAN_APART")) : -1;
+    const bool apart = next_it <= kMaxIter && (forced >= 0 ? forced != 0 : v.N >= 200);
+    hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), step_lds_bytes(v.N), s, v, next_it,
+                       apart ? 1 : 0);
+    if (apart) {
+        int parts = (v.N + 31) / 32;
+        parts = parts > 16 ? 16 : parts;
+        hipLaunchKernelGGL(k_step_hessian, dim3(v.nb * parts), dim3(kStageThreads),
+                           (kStageThreads / kWave) * kSliceDoubles * sizeof(real_t), s, v, parts);
+    }
 }
 bool tail_enabled(const BatchView& v) {
     return v.tailList != nullptr && v.wabs != nullptr && v.N <= kFastHorizonLarge;

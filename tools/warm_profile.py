@@ -6,7 +6,7 @@ import torch
 from nmpc_amd import synthetic as S
 from nmpc_amd.batch import Batch
 
-B, N, W = 4096, 100, int(os.environ.get("WARM", "10"))
+B, N, W = int(os.environ.get("PROF_B", "4096")), int(os.environ.get("PROF_N", "100")), int(os.environ.get("WARM", "10"))
 dev = torch.device("cuda:0")
 d = S.make_batch(B, N, extra_steps=W, seed=S.DEFAULT_SEED)
 refs = torch.from_numpy(np.ascontiguousarray(d["refs"])).to(dev)
