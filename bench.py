@@ -81,7 +81,8 @@ METRIC = "NMPC solves/sec (prep+feedback) at batch B, default horizon"
 #                 the first iteration; later iterations refactorise from the
 #                 last active-set change down, which is not counted here.
 #   newton_setup  per stage and iteration: gradient (0.38 kflop) + Hessian
-#                 blocks (4.7 kflop); reads C, c, z, y (1896 B), writes the
+#                 blocks (2.9 kflop: the lower triangle of the diagonal block, 84 entries of up
+#                 to 15 dyads, and the sub-diagonal block); reads C, c, z, y (1896 B), writes the
 #                 block row (228 values) and gradient (1920 B)
 #   newton_step / qp_begin  per stage and call: stage update, clipping,
 #                 objective; reads C, c and the 15-vectors, writes them back
@@ -89,7 +90,7 @@ ALGO = {
     "linearise": dict(flop=17000.0, bytes=1664.0),
     "newton_solve": dict(flop=840.0, bytes=4032.0),
     "newton_factor": dict(flop=4200.0, bytes=1824.0),
-    "newton_setup": dict(flop=5080.0, bytes=3816.0),
+    "newton_setup": dict(flop=3300.0, bytes=3816.0),
     "newton_step": dict(flop=670.0, bytes=3100.0),
     "qp_begin": dict(flop=260.0, bytes=1100.0),
 }
@@ -100,7 +101,8 @@ BOUND = {"linearise": "vector-alu", "newton_solve": "hbm", "qp_begin": "hbm", "n
 LIMITER = {
     "linearise": "vector instruction issue (FMA contraction is off: the ceiling is the FMA-free rate)",
     "newton_solve": "instruction issue of one wavefront per SIMD running one dependent chain per "
-                    "instance (from 512 instances on an iteration's solve is two overlapping "
+                    "instance (long sweeps: two wavefronts, factorisation and substitution, still one "
+                    "chain; from 512 instances on an iteration's solve is two overlapping "
                     "launches, long and short factorisation sweeps, each counted in full); HBM in the "
                     "launch that factorises every block and for batches that fill the chip twice over",
     "qp_begin": "HBM", "newton_step": "HBM",

@@ -193,3 +193,27 @@ def test_one_wavefront_sweep_in_a_fresh_process(port_built):
     assert len(lines) == 2, out.stdout[-2000:]
     for l in lines:
         assert " 0 mismatches" in l and "0 entries differ" in l, l
+
+
+@pytest.mark.gpu
+def test_hessian_rows_by_their_own_kernel_in_a_fresh_process(port_built):
+    """From 200 stages on the Newton step leaves the Hessian block rows of the next
+    set-up to a kernel of their own (several workgroups per instance);
+    NMPC_HESSIAN_APART=1 / 0 makes every horizon take that way / none: same results
+    both ways, at a short horizon with two-part iterations and at a long one,
+    checked by the soak tool in child processes because the switch is read once
+    per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for apart, runs in (("1", ["777", "30", "3", "5151", "24", "100", "2", "5154"]),
+                        ("0", ["20", "230", "2", "5155"]), ("1", ["20", "230", "2", "5155"])):
+        env = dict(os.environ, NMPC_HESSIAN_APART=apart, SOAK_DUMPS="8")
+        out = subprocess.run([sys.executable, os.path.join(root, "tests", "soak_warm.py")] + runs,
+                             env=env, capture_output=True, text=True, timeout=170)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if "mismatches" in l]
+        assert len(lines) == len(runs) // 4, out.stdout[-2000:]
+        for l in lines:
+            assert " 0 mismatches" in l and "0 entries differ" in l, l

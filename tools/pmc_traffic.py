@@ -19,11 +19,17 @@ import sys
 from collections import defaultdict
 
 SHORT = {"k_linearise": "linearise", "k_linearise_free": "linearise_free", "k_qp_begin": "qp_begin",
-         "k_newton_solve": "newton_solve", "k_newton_step": "newton_step",
+         "k_newton_solve": "newton_solve", "k_newton_solve_team": "newton_solve",
+         "k_newton_step": "newton_step", "k_step_hessian": "newton_step",
          "k_init_stages": "init_stages", "k_line_search_tail": "line_search_tail", "k_line_search_fast": "line_search_fast", "k_line_search_exact": "line_search_exact",
          "k_line_search_commit": "line_search_commit", "k_line_search_hessian": "line_search_hessian",
          "k_list_count": "list_count", "k_list_fill": "list_fill", "k_store_refs": "store_refs",
          "k_qp_finish": "qp_finish", "k_gather_results": "gather_results"}
+
+
+# Kernels that follow another one inside the same timed interval of the library: their bytes
+# count, their launches do not.
+FOLLOWERS = {"k_step_hessian"}
 
 
 def collect(path, counter):
@@ -47,16 +53,22 @@ def main():
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over the launches",
            "bytes_per_launch": {}, "read_bytes_per_launch": {}, "write_bytes_per_launch": {},
            "launches": {}}
+    # per name of the library's timers: the kernels of one name together
+    total = defaultdict(lambda: [0.0, 0.0, 0])
     for name in sorted(set(fetch) | set(write)):
         if name not in SHORT:
             continue
-        r = 2.0 * 1024.0 * sum(fetch.get(name, [0])) / max(1, len(fetch.get(name, [])))
-        w = 1024.0 * sum(write.get(name, [0])) / max(1, len(write.get(name, [])))
-        k = SHORT[name]
-        out["bytes_per_launch"][k] = round(r + w)
-        out["read_bytes_per_launch"][k] = round(r)
-        out["write_bytes_per_launch"][k] = round(w)
-        out["launches"][k] = len(fetch.get(name, []))
+        t = total[SHORT[name]]
+        t[0] += 2.0 * 1024.0 * sum(fetch.get(name, [0]))
+        t[1] += 1024.0 * sum(write.get(name, [0]))
+        if name not in FOLLOWERS:
+            t[2] += len(fetch.get(name, []))
+    for k, (r, w, n) in sorted(total.items()):
+        n = max(1, n)
+        out["bytes_per_launch"][k] = round((r + w) / n)
+        out["read_bytes_per_launch"][k] = round(r / n)
+        out["write_bytes_per_launch"][k] = round(w / n)
+        out["launches"][k] = n
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import hashlib
