@@ -232,7 +232,11 @@ int nmpc_batch_preparation_step(nmpc_batch_t *b);
  * (multipliers of the old linearisation are a worse start for the dual Newton
  * iteration than none).  After a feedback step that did not converge the
  * instance is left exactly as it is.  Results then differ from the
- * reference's; oracle/nmpc_port.c defines the arithmetic. */
+ * reference's; oracle/nmpc_port.c defines the arithmetic.  What it buys, in a
+ * closed loop of 4 096 instances against simulated vehicles over 200 control
+ * steps (tools/rti_closed_loop.py): mean position error 1.4 m instead of
+ * 4.7 m, at 44 % more time per control step and 88 % instead of 98 % of the
+ * solves ending with NMPC_OK within the iteration limit. */
 int nmpc_batch_set_rti(nmpc_batch_t *b, int enabled);
 
 /* Re-linearisation of every stage about the stored reference trajectory with
