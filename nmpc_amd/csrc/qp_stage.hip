@@ -1,5 +1,5 @@
-// Stage-parallel half of the dual Newton solve: one 256-thread workgroup per
-// controller instance.
+// Stage-parallel half of the dual Newton solve: one workgroup per controller
+// instance, of 256 threads, or of 1 024 in the form for long horizons.
 //
 //   k_qp_begin     initial-value embedding and the opening step
 //                  (ccs-c66x/cnmpc.c:675-702, qpDUNES/dual_qp.c:56-100),
@@ -40,11 +40,21 @@
 
 #pragma clang fp contract(off)
 
-// This file is compiled twice (qp_common.hpp, kOwnCfg); the two sets of kernels
-// and launchers live in two inline namespaces, and the launchers the library
-// calls (kernels.hpp) pick between them at the end of the first compilation.
-#if NMPC_OWN_CFG
+// This file is compiled four times: with the weights and bounds of the batch or
+// of each instance (qp_common.hpp, kOwnCfg), and with workgroups of 256 or of
+// 1 024 threads (NMPC_STAGE_THREADS).  The four sets of kernels and launchers live
+// in four inline namespaces, and the launchers the library calls (kernels.hpp)
+// pick between them at the end of the first compilation.
+#ifndef NMPC_STAGE_THREADS
+#define NMPC_STAGE_THREADS 256
+#endif
+#define NMPC_WIDE (NMPC_STAGE_THREADS != 256)
+#if NMPC_OWN_CFG && NMPC_WIDE
+#define NMPC_CFG_NS perinstance_wide
+#elif NMPC_OWN_CFG
 #define NMPC_CFG_NS perinstance
+#elif NMPC_WIDE
+#define NMPC_CFG_NS batchwide_wide
 #else
 #define NMPC_CFG_NS batchwide
 #endif
@@ -54,25 +64,31 @@ inline namespace NMPC_CFG_NS {
 
 namespace {
 
-constexpr int kStageThreads = 256;
+// The wide form is for launches of few instances with long horizons: at 500 stages
+// an instance's passes are 30 elements per thread of a 256-thread workgroup, and a
+// few hundred such workgroups leave most of the chip idle.
+constexpr int kStageThreads = NMPC_STAGE_THREADS;
+static_assert(kStageThreads == 256 || kStageThreads == 1024, "workgroups of 4 or 16 wavefronts");
+constexpr int kStageWaves = kStageThreads / kWave;
 // k_qp_begin waits on memory most of the time: six resident wavefronts per
 // SIMD (80 registers per lane, eight of them spilled) measured 7 % faster than
 // seven and 9 % faster than five (96 registers, no spills).  k_newton_step needs about
 // 120 registers; capping it lower spills and is slower.
 #ifndef NMPC_BEGIN_WAVES
-#define NMPC_BEGIN_WAVES 6
+#define NMPC_BEGIN_WAVES (NMPC_WIDE ? 4 : 6)
 #endif
 #define NMPC_BEGIN_OCC __attribute__((amdgpu_waves_per_eu(NMPC_BEGIN_WAVES, NMPC_BEGIN_WAVES)))
-constexpr int kStageChunk = 64;                 // stage slots whose z, q sit in LDS at once
-constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920: z + q, reused as sum buffer
+constexpr int kStageChunk = kStageThreads / 4;      // stage slots whose z, q sit in LDS at once
+constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920 (7680): z + q, reused as sum buffer
+constexpr int kRedDoubles = 2 + 2 * kStageWaves;    // a result, then two values per wavefront
 
-// dynamic LDS: buf[1920] | vals[N+1] | red[8] | chg[N+1] (int)
+// dynamic LDS: buf[kBufDoubles] | vals[N+1] | red[kRedDoubles] | chg[N+1] (int)
 struct StageLds {
     real_t* z;      // [64*15]
     real_t* q;      // [64*15]
     real_t* buf;    // = z, 1920 doubles for ordered sums
     real_t* vals;   // [N+1] stage objective values by slot
-    real_t* red;    // [8]
+    real_t* red;    // [kRedDoubles]
     int* chg;       // [N+1] active set of slot changed
     real_t* terms;  // [12 N] slope terms of the fused sweep (k_newton_step), or null
     real_t* sqr;    // [12 N] squared gradient rows of the same sweep
@@ -86,7 +102,7 @@ NMPC_DEV StageLds carve(real_t* base, int N) {
     L.buf = base;
     L.vals = base + kBufDoubles;
     L.red = L.vals + (N + 1);
-    L.chg = (int*)(L.red + 8);
+    L.chg = (int*)(L.red + kRedDoubles);
     L.terms = nullptr;
     L.sqr = nullptr;
     L.prevz = nullptr;
@@ -95,7 +111,7 @@ NMPC_DEV StageLds carve(real_t* base, int N) {
 
 // k_newton_step: room for the slope terms its first sweep produces on the way,
 // when the gradient fits one accumulation buffer.
-NMPC_DEV bool sweep_has_slope(int N) { return NX * N <= kBufDoubles; }
+NMPC_DEV bool sweep_has_slope(int N) { return NX * N <= 1920; }
 NMPC_DEV StageLds carve_step(real_t* base, int N) {
     StageLds L = carve(base, N);
     if (sweep_has_slope(N)) {
@@ -107,11 +123,11 @@ NMPC_DEV StageLds carve_step(real_t* base, int N) {
 }
 
 inline size_t stage_lds_bytes(int N) {
-    return (size_t)(kBufDoubles + (N + 1) + 8) * sizeof(real_t) + (size_t)(N + 1) * sizeof(int);
+    return (size_t)(kBufDoubles + (N + 1) + kRedDoubles) * sizeof(real_t) + (size_t)(N + 1) * sizeof(int);
 }
 inline size_t step_lds_bytes(int N) {
     const size_t base = (stage_lds_bytes(N) + 7) / 8 * 8;
-    return base + (NX * N <= kBufDoubles ? (size_t)(16 + 2 * NX * N) * sizeof(real_t) : 0);
+    return base + (NX * N <= 1920 ? (size_t)(16 + 2 * NX * N) * sizeof(real_t) : 0);
 }
 
 // acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order, by
@@ -204,7 +220,7 @@ NMPC_DEV real_t block_min(real_t x, const StageLds& L) {
     __syncthreads();
     real_t m = L.red[1];
 #pragma unroll
-    for (int w = 1; w < kStageThreads / kWave; w++) m = (L.red[1 + w] < m) ? L.red[1 + w] : m;
+    for (int w = 1; w < kStageWaves; w++) m = (L.red[1 + w] < m) ? L.red[1 + w] : m;
     __syncthreads();
     return m;
 }
@@ -212,12 +228,12 @@ NMPC_DEV real_t block_min(real_t x, const StageLds& L) {
 NMPC_DEV int block_max(int x, const StageLds& L) {
     x = wave_max(x);
     const int tid = threadIdx.x;
-    int* r = (int*)(L.red + 5);
+    int* r = (int*)(L.red + 1 + kStageWaves);
     if ((tid & 63) == 0) r[tid >> 6] = x;
     __syncthreads();
     int m = r[0];
 #pragma unroll
-    for (int w = 1; w < kStageThreads / kWave; w++) m = (r[w] > m) ? r[w] : m;
+    for (int w = 1; w < kStageWaves; w++) m = (r[w] > m) ? r[w] : m;
     __syncthreads();
     return m;
 }
@@ -1534,7 +1550,13 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_hessian(BatchView 
     }
 }
 
+// Dynamic LDS beyond the default cap of 64 KB has to be asked for.
+static void allow_lds(const void* kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 void qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
+    allow_lds((const void*)k_qp_begin, stage_lds_bytes(v.N));
     hipLaunchKernelGGL(k_qp_begin, dim3(v.nb), dim3(kStageThreads), stage_lds_bytes(v.N), s, v, meas);
 }
 void newton_step(const BatchView& v, int next_it, hipStream_t s) {
@@ -1542,13 +1564,15 @@ void newton_step(const BatchView& v, int next_it, hipStream_t s) {
     // costs what it saves (4 096 x 100: 5.15 against 5.17 ms).  NMPC_HESSIAN_APART=0 / 1: never / always.
     static const int forced = getenv("NMPC_HESSIAN_APART") ? atoi(getenv("NMPC_HESSIAN_APART")) : -1;
     const bool apart = next_it <= kMaxIter && (forced >= 0 ? forced != 0 : v.N >= 200);
+    allow_lds((const void*)k_newton_step, step_lds_bytes(v.N));
     hipLaunchKernelGGL(k_newton_step, dim3(v.nb), dim3(kStageThreads), step_lds_bytes(v.N), s, v, next_it,
                        apart ? 1 : 0);
     if (apart) {
         int parts = (v.N + 31) / 32;
         parts = parts > 16 ? 16 : parts;
+        allow_lds((const void*)k_step_hessian, kStageWaves * kSliceDoubles * sizeof(real_t));
         hipLaunchKernelGGL(k_step_hessian, dim3(v.nb * parts), dim3(kStageThreads),
-                           (kStageThreads / kWave) * kSliceDoubles * sizeof(real_t), s, v, parts);
+                           kStageWaves * kSliceDoubles * sizeof(real_t), s, v, parts);
     }
 }
 bool tail_enabled(const BatchView& v) {
@@ -1576,6 +1600,7 @@ void line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
         hipLaunchKernelGGL(k_line_search_tail, dim3(grid), dim3(kTailThreads), lds, s, v, next_it);
     } else {
         const int grid = v.nb < 2048 ? v.nb : 2048;
+        allow_lds((const void*)k_line_search_exact, stage_lds_bytes(v.N));
         hipLaunchKernelGGL(k_line_search_exact, dim3(grid), dim3(kStageThreads), stage_lds_bytes(v.N), s, v,
                            next_it);
     }
@@ -1583,6 +1608,7 @@ void line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     // and warm-started batches hand over half of their instances
     const int grid_commit = v.nb < 2048 ? v.nb : 2048;
     const int grid_hessian = v.nb < 512 ? v.nb : 512;
+    allow_lds((const void*)k_line_search_commit, stage_lds_bytes(v.N));
     hipLaunchKernelGGL(k_line_search_commit, dim3(grid_commit), dim3(kStageThreads),
                        stage_lds_bytes(v.N), s, v, next_it);
     if (next_it <= kMaxIter)
@@ -1592,24 +1618,54 @@ void line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
 
 }  // inline namespace
 
-#if !NMPC_OWN_CFG
-namespace perinstance {     // the second compilation of this file
-void qp_begin(const BatchView& v, const real_t* meas, hipStream_t s);
-void newton_step(const BatchView& v, int next_it, hipStream_t s);
-void line_search_tail(const BatchView& v, int next_it, hipStream_t s);
+#if !NMPC_OWN_CFG && !NMPC_WIDE
+#define NMPC_OTHER_COMPILATION(ns)                                                  \
+    namespace ns {                                                                  \
+    void qp_begin(const BatchView& v, const real_t* meas, hipStream_t s);           \
+    void newton_step(const BatchView& v, int next_it, hipStream_t s);               \
+    void line_search_tail(const BatchView& v, int next_it, hipStream_t s);          \
+    }
+NMPC_OTHER_COMPILATION(perinstance)
+NMPC_OTHER_COMPILATION(batchwide_wide)
+NMPC_OTHER_COMPILATION(perinstance_wide)
+#undef NMPC_OTHER_COMPILATION
+
+namespace {
+// Workgroups of 1 024 threads for the kernels that follow the first Newton solve,
+// where a launch of few instances with long horizons leaves most of the chip idle
+// (the opening kernel has every instance of the batch to work on and stays as it
+// is).  NMPC_WIDE_STAGE=0 / 1: never / always.
+bool wide_stage(const BatchView& v) {
+    static const int forced = getenv("NMPC_WIDE_STAGE") ? atoi(getenv("NMPC_WIDE_STAGE")) : -1;
+    if (!kDoublePrecision) return false;
+    // the long part of a two-part iteration, or a batch too small to have parts; a launch
+    // over every instance of a larger batch is bound by throughput and slower this way
+    return forced >= 0 ? forced != 0 : (v.N >= 200 && (v.listPart == 1 || (!v.list && v.nb <= 256)));
 }
+}  // namespace
+
 void launch_qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
     if (v.cfg) perinstance::qp_begin(v, meas, s);
     else batchwide::qp_begin(v, meas, s);
 }
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
-    if (v.cfg) perinstance::newton_step(v, next_it, s);
-    else batchwide::newton_step(v, next_it, s);
+    if (wide_stage(v)) {
+        if (v.cfg) perinstance_wide::newton_step(v, next_it, s);
+        else batchwide_wide::newton_step(v, next_it, s);
+    } else {
+        if (v.cfg) perinstance::newton_step(v, next_it, s);
+        else batchwide::newton_step(v, next_it, s);
+    }
 }
 bool line_search_tail_enabled(const BatchView& v) { return batchwide::tail_enabled(v); }
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
-    if (v.cfg) perinstance::line_search_tail(v, next_it, s);
-    else batchwide::line_search_tail(v, next_it, s);
+    if (wide_stage(v)) {
+        if (v.cfg) perinstance_wide::line_search_tail(v, next_it, s);
+        else batchwide_wide::line_search_tail(v, next_it, s);
+    } else {
+        if (v.cfg) perinstance::line_search_tail(v, next_it, s);
+        else batchwide::line_search_tail(v, next_it, s);
+    }
 }
 #endif
 

@@ -196,20 +196,22 @@ def test_one_wavefront_sweep_in_a_fresh_process(port_built):
 
 
 @pytest.mark.gpu
-def test_hessian_rows_by_their_own_kernel_in_a_fresh_process(port_built):
+def test_long_horizon_forms_in_fresh_processes(port_built):
     """From 200 stages on the Newton step leaves the Hessian block rows of the next
-    set-up to a kernel of their own (several workgroups per instance);
-    NMPC_HESSIAN_APART=1 / 0 makes every horizon take that way / none: same results
-    both ways, at a short horizon with two-part iterations and at a long one,
-    checked by the soak tool in child processes because the switch is read once
-    per process."""
+    set-up to a kernel of their own (several workgroups per instance), and the long
+    part of a two-part iteration (or a batch of at most 256 instances) runs its
+    stage kernels with workgroups of 1 024 threads instead of 256.
+    NMPC_HESSIAN_APART and NMPC_WIDE_STAGE = 1 / 0 make every launch take those
+    ways / none: same results either way, at a short horizon with two-part
+    iterations and at a long one, checked by the soak tool in child processes
+    because the switches are read once per process."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for apart, runs in (("1", ["777", "30", "3", "5151", "24", "100", "2", "5154"]),
-                        ("0", ["20", "230", "2", "5155"]), ("1", ["20", "230", "2", "5155"])):
-        env = dict(os.environ, NMPC_HESSIAN_APART=apart, SOAK_DUMPS="8")
+    for forced, runs in (("1", ["777", "30", "3", "5151", "24", "100", "2", "5154"]),
+                         ("0", ["20", "230", "2", "5155"]), ("1", ["20", "230", "2", "5155"])):
+        env = dict(os.environ, NMPC_HESSIAN_APART=forced, NMPC_WIDE_STAGE=forced, SOAK_DUMPS="8")
         out = subprocess.run([sys.executable, os.path.join(root, "tests", "soak_warm.py")] + runs,
                              env=env, capture_output=True, text=True, timeout=170)
         assert out.returncode == 0, out.stderr[-2000:]
