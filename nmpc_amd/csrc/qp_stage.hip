@@ -80,7 +80,7 @@ constexpr int kStageWaves = kStageThreads / kWave;
 #define NMPC_BEGIN_OCC __attribute__((amdgpu_waves_per_eu(NMPC_BEGIN_WAVES, NMPC_BEGIN_WAVES)))
 constexpr int kStageChunk = kStageThreads / 4;      // stage slots whose z, q sit in LDS at once
 constexpr int kBufDoubles = 2 * kStageChunk * NZ;   // 1920 (7680): z + q, reused as sum buffer
-constexpr int kRedDoubles = 2 + 3 * kStageWaves;    // a result, then up to three values per wavefront
+constexpr int kRedDoubles = 2 + 2 * kStageWaves;    // a result, then two values per wavefront
 
 // dynamic LDS: buf[kBufDoubles] | vals[N+1] | red[kRedDoubles] | chg[N+1] (int)
 struct StageLds {
@@ -90,7 +90,9 @@ struct StageLds {
     real_t* vals;   // [N+1] stage objective values by slot
     real_t* red;    // [kRedDoubles]
     int* chg;       // [N+1] active set of slot changed
-    real_t* prevz;  // [15] clipped point of the stage before the current chunk (k_newton_step), or null
+    real_t* terms;  // [12 N] slope terms of the fused sweep (k_newton_step), or null
+    real_t* sqr;    // [12 N] squared gradient rows of the same sweep
+    real_t* prevz;  // [15] clipped point of the stage before the current chunk
 };
 
 NMPC_DEV StageLds carve(real_t* base, int N) {
@@ -101,15 +103,22 @@ NMPC_DEV StageLds carve(real_t* base, int N) {
     L.vals = base + kBufDoubles;
     L.red = L.vals + (N + 1);
     L.chg = (int*)(L.red + kRedDoubles);
+    L.terms = nullptr;
+    L.sqr = nullptr;
     L.prevz = nullptr;
     return L;
 }
 
-// k_newton_step: its first sweep makes the gradient rows of a stage once the
-// successor's point is known, and keeps the last point of a chunk for the next.
+// k_newton_step: room for the slope terms its first sweep produces on the way,
+// when the gradient fits one accumulation buffer.
+NMPC_DEV bool sweep_has_slope(int N) { return NX * N <= 1920; }
 NMPC_DEV StageLds carve_step(real_t* base, int N) {
     StageLds L = carve(base, N);
-    L.prevz = (real_t*)L.chg + ((size_t)(N + 1) * sizeof(int) + 7) / 8 * (8 / sizeof(real_t));
+    if (sweep_has_slope(N)) {
+        L.prevz = (real_t*)L.chg + ((size_t)(N + 1) * sizeof(int) + 7) / 8 * (8 / sizeof(real_t));
+        L.terms = L.prevz + 16;
+        L.sqr = L.terms + NX * N;
+    }
     return L;
 }
 
@@ -117,7 +126,8 @@ inline size_t stage_lds_bytes(int N) {
     return (size_t)(kBufDoubles + (N + 1) + kRedDoubles) * sizeof(real_t) + (size_t)(N + 1) * sizeof(int);
 }
 inline size_t step_lds_bytes(int N) {
-    return (stage_lds_bytes(N) + 7) / 8 * 8 + 16 * sizeof(real_t);
+    const size_t base = (stage_lds_bytes(N) + 7) / 8 * 8;
+    return base + (NX * N <= 1920 ? (size_t)(16 + 2 * NX * N) * sizeof(real_t) : 0);
 }
 
 // acc + buf[0] + buf[1] + ... + buf[len-1], added strictly in that order, by
@@ -209,26 +219,22 @@ NMPC_DEV void wave_sums(real_t (&x)[sizeof...(I)], std::integer_sequence<int, I.
     for (int o = 32; o > 0; o >>= 1) ((x[I] += __shfl_xor(x[I], o)), ...);
 }
 
-// Sums over the workgroup of each thread's x[0 .. K-1], in no particular order.
-// Uniform result.
-template <int K>
-NMPC_DEV void block_sums(real_t (&x)[K], const StageLds& L) {
-    static_assert(K <= 3, "red holds three values per wavefront");
-    wave_sums(x, std::make_integer_sequence<int, K>{});
+// Sums over the workgroup of each thread's x[0] and x[1], in no particular
+// order.  Uniform result.
+NMPC_DEV void block_sums(real_t (&x)[2], const StageLds& L) {
+    wave_sums(x, std::make_integer_sequence<int, 2>{});
     const int tid = threadIdx.x;
     if ((tid & (kWave - 1)) == 0) {
-#pragma unroll
-        for (int i = 0; i < K; i++) L.red[K * (tid / kWave) + i] = x[i];
+        L.red[2 * (tid / kWave)] = x[0];
+        L.red[2 * (tid / kWave) + 1] = x[1];
     }
     __syncthreads();
+    real_t a = 0., b = 0.;
 #pragma unroll
-    for (int i = 0; i < K; i++) {
-        real_t a = 0.;
-#pragma unroll
-        for (int w = 0; w < kStageWaves; w++) a += L.red[K * w + i];
-        x[i] = a;
-    }
+    for (int w = 0; w < kStageWaves; w++) { a += L.red[2 * w]; b += L.red[2 * w + 1]; }
     __syncthreads();
+    x[0] = a;
+    x[1] = b;
 }
 
 NMPC_DEV real_t block_min(real_t x, const StageLds& L) {
@@ -353,14 +359,15 @@ NMPC_DEV int publish_changes(const BatchView& v, const Inst& I, const StageLds& 
 // lower triangle of the 12x12 diagonal block and add the free columns' dyads in
 // column order.
 // gradKept: grad already holds the gradient at z (a slope trial at the committed
-// step stored it); squaresKept: and this is the sum of its squared rows, added in
-// no particular order.
+// step stored it).
 // Returns false when the gradient norm passes the convergence test.
 NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& L, int it,
-                             bool gradKept, const real_t* squaresKept = nullptr) {
+                             bool gradKept, const real_t* normKept = nullptr) {
     const int tid = threadIdx.x, N = v.N, n = NX * N;
     bool converged;
-    {
+    if (gradKept && normKept) {
+        converged = sqrt(*normKept) < kStatTol;
+    } else {
         // The test asks one thing of the sum of the squared rows: is its root below the
         // tolerance.  The terms are not negative, so a sum in any order is within
         // (n - 1) u / (1 - (n - 1) u) of the exact one, relatively, as the row-ordered
@@ -368,25 +375,21 @@ NMPC_DEV bool setup_gradient(const BatchView& v, const Inst& I, const StageLds& 
         // with room for the roundings of the threshold's square and of the root) of the
         // squared tolerance it answers for the row-ordered sum, whose 5.3 ns per term
         // (32 microseconds at 500 stages) are then not spent.
-        real_t sq[1] = {0.};
-        if (gradKept && squaresKept) {
-            sq[0] = *squaresKept;
-        } else {
-            int r = tid;
-            for (; r + kStageThreads < n; r += 2 * kStageThreads) {     // two rows in flight
-                const real_t g0 = gradKept ? I.grad[r] : gradient_row(v, I, I.z, r);
-                const real_t g1 = gradKept ? I.grad[r + kStageThreads] : gradient_row(v, I, I.z, r + kStageThreads);
-                if (!gradKept) { I.grad[r] = g0; I.grad[r + kStageThreads] = g1; }
-                sq[0] += g0 * g0;
-                sq[0] += g1 * g1;
-            }
-            if (r < n) {
-                const real_t g = gradKept ? I.grad[r] : gradient_row(v, I, I.z, r);
-                if (!gradKept) I.grad[r] = g;
-                sq[0] += g * g;
-            }
-            block_sums(sq, L);
+        real_t sq[2] = {0., 0.};
+        int r = tid;
+        for (; r + kStageThreads < n; r += 2 * kStageThreads) {     // two rows in flight
+            const real_t g0 = gradKept ? I.grad[r] : gradient_row(v, I, I.z, r);
+            const real_t g1 = gradKept ? I.grad[r + kStageThreads] : gradient_row(v, I, I.z, r + kStageThreads);
+            if (!gradKept) { I.grad[r] = g0; I.grad[r + kStageThreads] = g1; }
+            sq[0] += g0 * g0;
+            sq[0] += g1 * g1;
         }
+        if (r < n) {
+            const real_t g = gradKept ? I.grad[r] : gradient_row(v, I, I.z, r);
+            if (!gradKept) I.grad[r] = g;
+            sq[0] += g * g;
+        }
+        block_sums(sq, L);
         const real_t tol2 = kStatTol * kStatTol;
         const real_t rel = (real_t)(4.0 * (double)n * kUnitRoundoff);
         const real_t edge = (real_t)(64.0 * kUnitRoundoff);
@@ -566,8 +569,8 @@ NMPC_DEV void assemble_hessian(const BatchView& v, const Inst& I, real_t* slices
 }
 
 NMPC_DEV void newton_setup(const BatchView& v, const Inst& I, const StageLds& L, int it,
-                           bool gradKept = false, const real_t* squaresKept = nullptr) {
-    if (setup_gradient(v, I, L, it, gradKept, squaresKept))
+                           bool gradKept = false, const real_t* normKept = nullptr) {
+    if (setup_gradient(v, I, L, it, gradKept, normKept))
         assemble_hessian<kStageThreads / kWave>(v, I, L.buf);
 }
 
@@ -699,7 +702,7 @@ NMPC_DEV void commit_kept_trial(const BatchView& v, const Inst& I, real_t a, con
 NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, real_t alpha,
                           int lsIter, int nextIt, const real_t* keptObjective = nullptr,
                           bool gradKept = false, bool withHessian = true,
-                          const real_t* squaresKept = nullptr) {
+                          const real_t* normKept = nullptr) {
     const int tid = threadIdx.x, n = NX * v.N;
     for (int r = tid; r < n; r += kStageThreads) {
         real_t* lp = I.lam + (size_t)lam_slot(v, r / NX) * NX + r % NX;
@@ -721,8 +724,8 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
     }
     if (nextIt <= kMaxIter) {
         __syncthreads();
-        if (withHessian) newton_setup(v, I, L, nextIt, gradKept && keptObjective, squaresKept);
-        else setup_gradient(v, I, L, nextIt, gradKept && keptObjective, squaresKept);
+        if (withHessian) newton_setup(v, I, L, nextIt, gradKept && keptObjective, normKept);
+        else setup_gradient(v, I, L, nextIt, gradKept && keptObjective);
     }
 }
 
@@ -737,17 +740,15 @@ NMPC_DEV void commit_step(const BatchView& v, const Inst& I, const StageLds& L, 
 // Newton set-up, and they read each Jacobian block while the direction pass
 // has just fetched it.  Stages are visited in horizon order, kStageChunk at a
 // time; the rows of a stage are done once its successor's point is known.
-// Returns the trial objective; *aminOut the smallest step; sums[0 .. 2]: the slope
-// terms at the full step, their magnitudes and the squared gradient rows, each
-// added in no particular order (what they are compared with decides whether
-// the row-ordered sum is needed: slope_decided, setup_gradient); grad is written
-// when keepGrad.
+// Returns the trial objective; *aminOut the smallest step; with L.terms:
+// *slopeOut the slope at the full step, and grad is written when keepGrad.
 NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I, const StageLds& L,
-                                               bool keepGrad, real_t* aminOut, real_t (&sums)[3]) {
+                                               bool keepGrad, real_t* aminOut, real_t* slopeOut,
+                                               real_t* normOut) {
     const int tid = threadIdx.x, N = v.N;
     const real_t a = 1.;
+    const bool rows = L.terms != nullptr;
     real_t amin = kInfty;
-    real_t part[3] = {0., 0., 0.};
     for (int c0 = 0; c0 <= N; c0 += kStageChunk) {
         const int c1 = (c0 + kStageChunk <= N + 1) ? c0 + kStageChunk : N + 1;
         for (int idx = tid; idx < (c1 - c0) * NZ; idx += kStageThreads) {
@@ -814,7 +815,7 @@ NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I
             else
                 L.vals[k] = stage_value(k < N ? v.H : v.Ht, L.z + (k - c0) * NZ, L.q + (k - c0) * NZ, pt, nV);
         }
-        {
+        if (rows) {
             // gradient rows of the stages whose successor is in LDS now
             const int kFirst = c0 > 0 ? c0 - 1 : 0;
             for (int rr = tid; rr < (c1 - 1 - kFirst) * NX; rr += kStageThreads) {
@@ -828,27 +829,28 @@ NMPC_DEV real_t directions_and_full_step_trial(const BatchView& v, const Inst& I
                 g += I.c[s * NX + i];
                 g -= L.z[(k + 1 - c0) * NZ + i];
                 if (keepGrad) I.grad[k * NX + i] = g;
-                const real_t t = g * I.dl[k * NX + i];
-                part[0] += t;
-                part[1] += fabs(t);
-                part[2] += g * g;
+                L.terms[k * NX + i] = g * I.dl[k * NX + i];
+                L.sqr[k * NX + i] = g * g;
             }
         }
         __syncthreads();
-        if (c1 <= N) {                          // the last stage of this chunk, for the next one
+        if (rows && c1 <= N) {                  // the last stage of this chunk, for the next one
             if (tid < NZ) L.prevz[tid] = L.z[(c1 - 1 - c0) * NZ + tid];
             __syncthreads();
         }
     }
-    block_sums(part, L);
-    sums[0] = part[0]; sums[1] = part[1]; sums[2] = part[2];
-    // objective: stage values in horizon order
-    if (tid < 16) {                 // one DPP row
-        const real_t sv = accumulate_by_row(0., L.vals, N + 1);
-        if (tid == 0) L.red[0] = sv;
+    // objective (stage values in horizon order), slope and squared gradient norm,
+    // side by side
+    if (tid < 3 * 16) {             // one DPP row each
+        const int w = tid >> 4;
+        const real_t* src = (w == 0 || !rows) ? L.vals : (w == 1 ? L.terms : L.sqr);
+        const real_t sv = accumulate_by_row(0., src, (w == 0 || !rows) ? N + 1 : NX * N);
+        if ((tid & 15) == 0) L.red[w] = sv;
     }
     __syncthreads();
     const real_t obj = L.red[0];
+    *slopeOut = L.red[1];
+    *normOut = L.red[2];
     __syncthreads();                            // block_min reuses red[1..]
     *aminOut = block_min(amin, L);
     return obj;
@@ -935,8 +937,6 @@ __global__ __launch_bounds__(kStageThreads) NMPC_BEGIN_OCC void k_qp_begin(Batch
 
 // ------------------------------------------------------------------------
 // hessianApart: the Hessian block rows of the next set-up are left to k_step_hessian.
-// (About 150 registers, three wavefronts per SIMD: held to four, 127 registers, the step
-// of 4 096 x 100 takes 0.35 instead of 0.28 ms.)
 __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int nextIt, int hessianApart) {
     extern __shared__ real_t lds_raw[];
     const StageLds L = carve_step(lds_raw, v.N);
@@ -950,15 +950,16 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
 
     for (int s = tid; s <= N; s += kStageThreads) L.chg[s] = 0;
 
-    real_t alphaMinAS;
-    real_t fullStep[3];                         // slope terms, their magnitudes, squared gradient rows: unordered sums
+    real_t alphaMinAS, fullStepSlope, fullStepNorm2;
     const bool keepGrad = nextIt <= kMaxIter;   // the last iteration leaves the gradient record alone
+    const bool haveSlope = L.terms != nullptr;
     // z and y hold the value trial at step length zAlpha, whose objective is objKept
-    real_t objKept = directions_and_full_step_trial(v, I, L, keepGrad, &alphaMinAS, fullStep);
+    real_t objKept = directions_and_full_step_trial(v, I, L, keepGrad, &alphaMinAS, &fullStepSlope,
+                                                    &fullStepNorm2);
     real_t zAlpha = 1.;
     // step length whose gradient grad holds, if any
-    real_t gradAlpha = keepGrad ? 1. : __builtin_nan("");
-    bool gradFromSweep = keepGrad;              // false once a slope trial rewrites grad
+    real_t gradAlpha = (haveSlope && keepGrad) ? 1. : __builtin_nan("");
+    bool gradFromSweep = haveSlope && keepGrad;     // false once a slope trial rewrites grad
 
     real_t alpha;
     int lsIter = 0;
@@ -982,7 +983,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
             if (nd * (alpha - (real_t)0.) < kEqTol) { alpha = 0.; st = ST_LS_MIN_STEP; break; }
         }
         if (st == ST_LS_MIN_STEP) {
-            if (keepGrad) {
+            if (haveSlope && keepGrad) {
                 // The solve ends here, and the reference's gradient record is still the
                 // one of this iteration's set-up, which the sweep above has replaced with
                 // the full step's: make it again from the committed point, clip(zUnc)
@@ -1017,16 +1018,9 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
         // search's two questions unless the sum sits within rounding of the tolerance
         // (slope_decided); only then are they added in row order.
         auto trial = [&](real_t at) {
-            if (at == 1.) {                         // the first sweep made the sums
-                bool flat, neg;
-                bool settled = slope_decided(fullStep[0], fullStep[1], n, normal, &flat, &neg);
-#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS         // test builds: both ways
-                if (nextIt & 2) settled = false;
-#endif
-                if (settled) {
-                    advance_decided(bs, flat, neg);
-                    return;
-                }
+            if (haveSlope && at == 1.) {            // the first sweep made it
+                advance(bs, fullStepSlope, normal);
+                return;
             }
             const real_t* zs = I.z;
             bool keep = false;
@@ -1090,7 +1084,7 @@ __global__ __launch_bounds__(kStageThreads) void k_newton_step(BatchView v, int 
     // grad can only be the first sweep's here when it belongs to the full step
     commit_step(v, I, L, alpha, lsIter, nextIt, (alpha == zAlpha) ? &objKept : nullptr,
                 alpha == gradAlpha, !hessianApart,
-                (gradFromSweep && alpha == 1.) ? &fullStep[2] : nullptr);
+                (haveSlope && gradFromSweep && alpha == 1.) ? &fullStepNorm2 : nullptr);
 }
 
 // Newton Hessian block rows after a k_newton_step that left them out, `parts`
