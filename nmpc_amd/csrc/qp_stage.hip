@@ -1151,8 +1151,14 @@ constexpr int kFastHorizonSmall = 124, kFastHorizonLarge = 508;
 constexpr int kFastBoxed = 3 * kFastHorizonLarge + NX;
 static_assert(3 * kFastHorizonSmall + NX <= 6 * kWave, "bounded variables must fit the wavefront");
 
+// Few searches in a launch (at most kFewSearches) are a matter of latency, not of
+// throughput: k_line_search_few takes them, one 1 024-thread workgroup each, and the
+// kernels for many leave them alone (fewTaken: that kernel runs in front of this one).
+constexpr int kFewSearches = 128;
+
 template <int kFastSlots>
-__global__ __launch_bounds__(kFastSlots ? 256 : kWave) void k_line_search_fast(BatchView v, int nextIt) {
+__global__ __launch_bounds__(kFastSlots ? 256 : kWave) void k_line_search_fast(BatchView v, int nextIt,
+                                                                                int fewTaken) {
     __shared__ real_t box[kFastSlots ? 1 : 5][kFastSlots ? 1 : kFastBoxed];
     constexpr int kWavesPerBlock = kFastSlots ? 4 : 1;
     const int lane = threadIdx.x & (kWave - 1);
@@ -1160,6 +1166,7 @@ __global__ __launch_bounds__(kFastSlots ? 256 : kWave) void k_line_search_fast(B
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int N = v.N, n = NX * N, eEnd = NZ * N + NX, nBounded = 3 * N + NX;
     const int count = __builtin_amdgcn_readfirstlane(v.tailCount[nextIt - 2]);
+    if (fewTaken && count <= kFewSearches) return;
     const int s0 = stage_slot(v, 0);
     for (int item = wave; item < count; item += nwaves) {
         const int b = __builtin_amdgcn_readfirstlane(v.tailList[item]);    // uniform: addresses stay scalar
@@ -1594,11 +1601,12 @@ __global__ __launch_bounds__(kStageThreads) void k_line_search_commit(BatchView 
     const int count = v.tailCount[nextIt - 2];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         Inst I = instance(v, v.tailList[item]);
+        if (I.sc->lsDeferred != 1) continue;        // k_line_search_few has done it all (uniform)
         const real_t alpha = I.sc->alpha;
         const int lsIter = I.sc->lsIter;
         for (int s = tid; s <= v.N; s += kStageThreads) L.chg[s] = 0;
         __syncthreads();
-        if (tid == 0) I.sc->lsDeferred = 0;
+        if (tid == 0) I.sc->lsDeferred = 2;         // committed, Hessian block rows to come
         commit_step(v, I, L, alpha, lsIter, nextIt, nullptr, false, false);
         __syncthreads();
     }
@@ -1611,9 +1619,197 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_hessian(BatchView 
     const int count = v.tailCount[nextIt - 2];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         Inst I = instance(v, v.tailList[item]);
+        if (I.sc->lsDeferred != 2) continue;        // not k_line_search_commit's (uniform)
         if (I.sc->status == ST_RUNNING) assemble_hessian<kTailThreads / kWave>(v, I, lds_raw);
+        __syncthreads();
+        if (threadIdx.x == 0) I.sc->lsDeferred = 0;
     }
 }
+
+#if NMPC_WIDE
+// ------------------------------------------------------------------------
+// k_line_search_fast's attempt at one search by a workgroup of sixteen wavefronts.
+// All of them share the pass over the stage vectors; the bounded variables go to LDS;
+// in a round, wavefront w < 14 adds up half of the bounded variables' terms for trial
+// point w / 2, and every wavefront then takes the fourteen parts in the same order
+// and goes through the same decisions, so the search state stays identical on all
+// of them without being exchanged (one barrier per round).  The sums are grouped
+// differently from k_line_search_fast's, which the rounding bound covers like any
+// other order.  Every thread returns whether the search is left open.
+// lds: 5 (3 N + 12) + 4 * 16 + 32 values.
+NMPC_DEV bool team_search(const BatchView& v, const Inst& I, int b, int nextIt, real_t* lds) {
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+    const int N = v.N, n = NX * N, eEnd = NZ * N + NX, nBounded = 3 * N + NX;
+    real_t* box = lds;                              // [5][nBounded]
+    real_t* share = lds + 5 * nBounded;             // [4 kStageWaves]
+    real_t* psum = share + 4 * kStageWaves;         // [2][16], by round parity
+    const int s0 = stage_slot(v, 0);
+    Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
+    const real_t normal = I.sc->lsNormal;
+    settle(bs);
+    real_t ahi = 1.;
+    if (bs.aMax > ahi) ahi = bs.aMax;
+    if (bs.aMin > ahi) ahi = bs.aMin;
+
+    // the variables without finite bounds: A, B and their share of M
+    real_t fixed[3] = {0., 0., 0.};
+    bool nearBound = false;
+    for (int e0 = tid; e0 < eEnd; e0 += 2 * kStageThreads) {
+        real_t fzu[2], fdz[2], fw[2], flo[2], fup[2], fa[2];
+        bool on[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = e0 + i * kStageThreads, s = e / NZ, j = e - s * NZ;
+            on[i] = e < eEnd && j < NX && s != s0;
+            const int ec = on[i] ? e : 0, ea = on[i] ? s * kWabsStride + j : 0;
+            fzu[i] = I.zUnc[ec]; fdz[i] = I.dz[ec]; fw[i] = I.qStep[ec];
+            flo[i] = I.zLow[ec]; fup[i] = I.zUpp[ec]; fa[i] = I.wabs[ea];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (!on[i]) continue;
+            nearBound = nearBound || clips(fzu[i], flo[i], fup[i]) || clips(fzu[i] + ahi * fdz[i], flo[i], fup[i]);
+            fixed[0] += fw[i] * fzu[i];
+            fixed[1] += fw[i] * fdz[i];
+            fixed[2] += fa[i] * (fabs(fzu[i]) + ahi * fabs(fdz[i]));
+        }
+    }
+    for (int s = tid; s <= N; s += kStageThreads) {
+        fixed[0] += I.pStep[s];
+        fixed[2] += I.wabs[s * kWabsStride + NZ];
+    }
+    // the bounded ones (the state of stage 0, then the controls) into LDS
+    for (int c = tid; c < nBounded; c += kStageThreads) {
+        const int k = c < NX ? 0 : (c - NX) / NU;
+        const int j = c < NX ? c : NX + (c - NX) - k * NU;
+        const int s = stage_slot(v, k), e = s * NZ + j;
+        const real_t zu = I.zUnc[e], dz = I.dz[e], lo = I.zLow[e], up = I.zUpp[e];
+        box[c] = zu; box[nBounded + c] = dz; box[2 * nBounded + c] = lo; box[3 * nBounded + c] = up;
+        box[4 * nBounded + c] = I.qStep[e];
+        real_t y0, y1;
+        const real_t z0 = fabs(clip_gap(zu, lo, up, &y0, &y1));
+        const real_t z1 = fabs(clip_gap(zu + ahi * dz, lo, up, &y0, &y1));
+        fixed[2] += I.wabs[s * kWabsStride + j] * (z0 > z1 ? z0 : z1);
+    }
+    wave_sums(fixed, std::make_integer_sequence<int, 3>{});
+    const bool nearAny = __builtin_amdgcn_ballot_w64(nearBound) != 0;
+    if (lane == 0) {
+        share[4 * w] = fixed[0]; share[4 * w + 1] = fixed[1]; share[4 * w + 2] = fixed[2];
+        share[4 * w + 3] = nearAny ? 1. : 0.;
+    }
+    __syncthreads();
+    fixed[0] = fixed[1] = fixed[2] = 0.;
+    nearBound = false;
+    if (lane < kStageWaves) {
+        fixed[0] = share[4 * lane]; fixed[1] = share[4 * lane + 1]; fixed[2] = share[4 * lane + 2];
+        nearBound = share[4 * lane + 3] != 0.;
+    }
+    wave_sums(fixed, std::make_integer_sequence<int, 3>{});
+    const real_t partA = fixed[0], partB = fixed[1], bound = fixed[2];
+    bool open = __builtin_amdgcn_ballot_w64(nearBound) != 0;
+
+    real_t at[kTailPoints];
+    auto plan_round = [&]() {       // as in k_line_search_fast
+        const real_t at1 = bs.done ? (real_t)0. : trial_alpha(bs);
+#pragma unroll
+        for (int i = 1; i <= kTailPoints; i++) {
+            Bisection st = bs;
+            const int depth = 31 - __builtin_clz(i);
+#pragma unroll
+            for (int d = depth - 1; d >= 0; d--)
+                if (!st.done) advance_assuming(st, ((i >> d) & 1) == 0);
+            at[i - 1] = st.done ? at1 : trial_alpha(st);
+        }
+    };
+    const int point = w >> 1;
+    const int mid = (nBounded + 1) / 2;
+    const int cFrom = (w & 1) ? mid : 0, cTo = (w & 1) ? nBounded : mid;
+    for (int round = 0; !bs.done && !open; ++round) {
+        plan_round();
+        real_t* part = psum + (round & 1) * 16;
+        if (w < 2 * kTailPoints) {
+            real_t atp = at[0];
+#pragma unroll
+            for (int q = 1; q < kTailPoints; q++) atp = (q == point) ? at[q] : atp;
+            real_t mine[1] = {0.};
+            for (int c = cFrom + lane; c < cTo; c += kWave) {
+                real_t y0, y1;
+                mine[0] += box[4 * nBounded + c] *
+                           clip_gap(box[c] + atp * box[nBounded + c], box[2 * nBounded + c], box[3 * nBounded + c], &y0, &y1);
+            }
+            wave_sums(mine, std::make_integer_sequence<int, 1>{});
+            if (lane == 0) part[w] = mine[0];
+        }
+        __syncthreads();
+        real_t sums[kTailPoints];
+#pragma unroll
+        for (int p = 0; p < kTailPoints; p++) {
+            sums[p] = part[2 * p] + part[2 * p + 1];
+            sums[p] += partA + at[p] * partB;
+        }
+        int node = 1;
+#pragma unroll
+        for (int level = 0; level < kTailDepth; level++) {
+            if (!bs.done && !open) {
+                real_t sv = sums[0];
+#pragma unroll
+                for (int q = 1; q < kTailPoints; q++) sv = (q == node - 1) ? sums[q] : sv;
+                bool flat, neg;
+                bool settled = slope_decided(sv, bound, n + eEnd + 64, normal, &flat, &neg);
+#ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS
+                if (bs.it & 1) settled = false;     // test build: exercise the hand-over
+#endif
+                if (settled) {
+                    advance_decided(bs, flat, neg);
+                    node = 2 * node + (neg ? 0 : 1);
+                } else {
+                    open = true;
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        Scalars* sc = I.sc;
+        if (open) {
+            sc->lsMin = bs.aMin; sc->lsMax = bs.aMax; sc->lsMid = bs.aMid;
+            sc->lsIter = bs.it;
+            sc->lsPhase = bs.phase;
+            const int to = atomicAdd(&v.tailCount[8 + nextIt - 2], 1);
+            v.tailList[v.B + to] = b;
+        } else {
+            sc->alpha = bs.alpha;
+            sc->lsIter = bs.it;
+        }
+    }
+    __syncthreads();
+    return open;
+}
+
+// At most kFewSearches searches in the launch: each gets a workgroup of sixteen
+// wavefronts for the first attempt, the commit of the step and the next Newton
+// set-up with its Hessian block rows (what k_line_search_fast, _commit and _hessian
+// do in three launches).  A search the first attempt leaves open stays handed over:
+// k_line_search_tail, _commit and _hessian take it as they do when there are many.
+__global__ __launch_bounds__(kStageThreads) void k_line_search_few(BatchView v, int nextIt) {
+    extern __shared__ real_t lds_raw[];
+    const int tid = threadIdx.x;
+    const int count = v.tailCount[nextIt - 2];
+    if (count > kFewSearches) return;
+    const StageLds L = carve(lds_raw, v.N);         // (the search is done with the LDS when the commit begins)
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const int b = v.tailList[item];
+        Inst I = instance(v, b);
+        if (team_search(v, I, b, nextIt, lds_raw)) continue;    // uniform
+        const real_t alpha = I.sc->alpha;
+        const int lsIter = I.sc->lsIter;
+        for (int s = tid; s <= v.N; s += kStageThreads) L.chg[s] = 0;
+        __syncthreads();
+        if (tid == 0) I.sc->lsDeferred = 0;
+        commit_step(v, I, L, alpha, lsIter, nextIt, nullptr, false, true);
+        __syncthreads();
+    }
+}
+#endif
 
 // Dynamic LDS beyond the default cap of 64 KB has to be asked for.
 static void allow_lds(const void* kernel, size_t bytes) {
@@ -1643,13 +1839,22 @@ void newton_step(const BatchView& v, int next_it, hipStream_t s) {
 bool tail_enabled(const BatchView& v) {
     return v.tailList != nullptr && v.wabs != nullptr && v.N <= kFastHorizonLarge;
 }
-void line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
+#if NMPC_WIDE
+void line_search_few(const BatchView& v, int next_it, hipStream_t s) {
+    const int grid = v.nb < kFewSearches ? v.nb : kFewSearches;
+    const size_t search = (size_t)(5 * (3 * v.N + NX) + 4 * kStageWaves + 32) * sizeof(real_t);
+    const size_t lds = stage_lds_bytes(v.N) > search ? stage_lds_bytes(v.N) : search;
+    allow_lds((const void*)k_line_search_few, lds);
+    hipLaunchKernelGGL(k_line_search_few, dim3(grid), dim3(kStageThreads), lds, s, v, next_it);
+}
+#endif
+void line_search_tail(const BatchView& v, int next_it, hipStream_t s, bool few_taken) {
     const dim3 grid_fast((v.nb + 3) / 4);
     if (kFirstAttempt) {
         if (v.N <= kFastHorizonSmall)
-            hipLaunchKernelGGL(k_line_search_fast<6>, grid_fast, dim3(256), 0, s, v, next_it);
+            hipLaunchKernelGGL(k_line_search_fast<6>, grid_fast, dim3(256), 0, s, v, next_it, few_taken ? 1 : 0);
         else
-            hipLaunchKernelGGL(k_line_search_fast<0>, dim3(v.nb), dim3(kWave), 0, s, v, next_it);
+            hipLaunchKernelGGL(k_line_search_fast<0>, dim3(v.nb), dim3(kWave), 0, s, v, next_it, few_taken ? 1 : 0);
     }
     // what the first attempt left open
     if (v.N <= kTailMaxHorizon) {
@@ -1688,7 +1893,8 @@ void line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     namespace ns {                                                                  \
     void qp_begin(const BatchView& v, const real_t* meas, hipStream_t s);           \
     void newton_step(const BatchView& v, int next_it, hipStream_t s);               \
-    void line_search_tail(const BatchView& v, int next_it, hipStream_t s);          \
+    void line_search_tail(const BatchView& v, int next_it, hipStream_t s, bool few_taken); \
+    void line_search_few(const BatchView& v, int next_it, hipStream_t s);           \
     }
 NMPC_OTHER_COMPILATION(perinstance)
 NMPC_OTHER_COMPILATION(batchwide_wide)
@@ -1724,12 +1930,20 @@ void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
 }
 bool line_search_tail_enabled(const BatchView& v) { return batchwide::tail_enabled(v); }
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
+    // k_line_search_few in front: the device decides by the number of searches which
+    // kernels take them (NMPC_FEW_SEARCHES=0: always the kernels for many)
+    static const bool few = !(getenv("NMPC_FEW_SEARCHES") && atoi(getenv("NMPC_FEW_SEARCHES")) == 0);
+    const bool taken = few && kDoublePrecision && v.N <= 508;       // kFastHorizonLarge
+    if (taken) {
+        if (v.cfg) perinstance_wide::line_search_few(v, next_it, s);
+        else batchwide_wide::line_search_few(v, next_it, s);
+    }
     if (wide_stage(v)) {
-        if (v.cfg) perinstance_wide::line_search_tail(v, next_it, s);
-        else batchwide_wide::line_search_tail(v, next_it, s);
+        if (v.cfg) perinstance_wide::line_search_tail(v, next_it, s, taken);
+        else batchwide_wide::line_search_tail(v, next_it, s, taken);
     } else {
-        if (v.cfg) perinstance::line_search_tail(v, next_it, s);
-        else batchwide::line_search_tail(v, next_it, s);
+        if (v.cfg) perinstance::line_search_tail(v, next_it, s, taken);
+        else batchwide::line_search_tail(v, next_it, s, taken);
     }
 }
 #endif

@@ -202,7 +202,8 @@ def test_long_horizon_forms_in_fresh_processes(port_built):
     part of a two-part iteration (or a batch of at most 256 instances) runs its
     stage kernels with workgroups of 1 024 threads instead of 256.
     NMPC_HESSIAN_APART and NMPC_WIDE_STAGE = 1 / 0 make every launch take those
-    ways / none: same results either way, at a short horizon with two-part
+    ways / none, and NMPC_FEW_SEARCHES=0 keeps a launch's step-length searches with
+    the kernels for many however few they are: same results either way, at a short horizon with two-part
     iterations and at a long one, checked by the soak tool in child processes
     because the switches are read once per process."""
     import os
@@ -211,7 +212,8 @@ def test_long_horizon_forms_in_fresh_processes(port_built):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for forced, runs in (("1", ["777", "30", "3", "5151", "24", "100", "2", "5154"]),
                          ("0", ["20", "230", "2", "5155"]), ("1", ["20", "230", "2", "5155"])):
-        env = dict(os.environ, NMPC_HESSIAN_APART=forced, NMPC_WIDE_STAGE=forced, SOAK_DUMPS="8")
+        env = dict(os.environ, NMPC_HESSIAN_APART=forced, NMPC_WIDE_STAGE=forced, NMPC_FEW_SEARCHES=forced,
+                   SOAK_DUMPS="8")
         out = subprocess.run([sys.executable, os.path.join(root, "tests", "soak_warm.py")] + runs,
                              env=env, capture_output=True, text=True, timeout=170)
         assert out.returncode == 0, out.stderr[-2000:]
