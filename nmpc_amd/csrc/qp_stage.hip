@@ -1850,7 +1850,8 @@ void line_search_few(const BatchView& v, int next_it, hipStream_t s) {
 #endif
 void line_search_tail(const BatchView& v, int next_it, hipStream_t s, bool few_taken) {
     const dim3 grid_fast((v.nb + 3) / 4);
-    if (kFirstAttempt) {
+    // (a batch of at most kFewSearches instances never has more searches than that)
+    if (kFirstAttempt && !(few_taken && v.nb <= kFewSearches)) {
         if (v.N <= kFastHorizonSmall)
             hipLaunchKernelGGL(k_line_search_fast<6>, grid_fast, dim3(256), 0, s, v, next_it, few_taken ? 1 : 0);
         else
