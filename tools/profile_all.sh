@@ -4,7 +4,7 @@
 #   and of warm control steps; HBM traffic per launch (separate --pmc passes); the VALU
 #   instruction mix of the stage linearisation.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-run}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
