@@ -736,8 +736,8 @@ int nmpc_batch_relinearise(nmpc_batch_t* b) {
 namespace {
 
 // Newton system, step and step-length searches of iteration `it` for the instances of view v.
-int newton_iteration(nmpc_batch* b, const BatchView& v, int it, hipStream_t s) {
-    TRY(timed_on(b, s, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, s); }));
+int newton_iteration(nmpc_batch* b, const BatchView& v, int it, hipStream_t s, bool cold) {
+    TRY(timed_on(b, s, NMPC_K_NEWTON_SOLVE, [&] { launch_newton_solve(v, s, cold); }));
     TRY(timed_on(b, s, NMPC_K_NEWTON_STEP, [&] { launch_newton_step(v, it + 1, s); }));
     if (line_search_tail_enabled(v))
         TRY(timed_on(b, s, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, s); }));
@@ -786,13 +786,13 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
             HIP_TRY(hipStreamWaitEvent(b->side_stream, b->fork_event, 0));
             // Whatever fails from here on, the second stream is joined back before the
             // call returns: nothing queued on it may outlive the order of the batch's stream.
-            const int rc_long = newton_iteration(b, solve_list_view(v, b->solve_lists, 1), it, b->stream);
+            const int rc_long = newton_iteration(b, solve_list_view(v, b->solve_lists, 1), it, b->stream, all_fresh);
             int rc_short;
             {
                 // intervals timed on the other stream do not continue the ones of this stream
                 hipEvent_t kept = b->chain_event;
                 b->chain_launches = false;
-                rc_short = newton_iteration(b, solve_list_view(v, b->solve_lists, 2), it, b->side_stream);
+                rc_short = newton_iteration(b, solve_list_view(v, b->solve_lists, 2), it, b->side_stream, all_fresh);
                 b->chain_launches = true;
                 b->chain_event = kept;
             }
@@ -817,7 +817,7 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
             if (line_search_tail_enabled(v))
                 TRY(timed(b, NMPC_K_LINE_SEARCH_TAIL, [&] { launch_line_search_tail(v, it + 1, b->stream); }));
         } else {
-            TRY(newton_iteration(b, v, it, b->stream));
+            TRY(newton_iteration(b, v, it, b->stream, all_fresh));
         }
     }
     TRY(timed(b, NMPC_K_OTHER, [&] { launch_qp_finish(v, b->stream); }));

@@ -39,7 +39,9 @@ void launch_qp_begin(const BatchView& v, const real_t* meas, hipStream_t s);
 bool newton_solve_two_waves(const BatchView& v);
 void launch_list_solves(const BatchView& v, unsigned epoch, hipStream_t s);
 BatchView solve_list_view(const BatchView& v, unsigned epoch, int part);
-void launch_newton_solve(const BatchView& v, hipStream_t s);
+// few_searches: the step-length searches of this solve are expected to be few (a solve after a
+// linearisation of every stage); the single-precision library only then runs a listed part as teams
+void launch_newton_solve(const BatchView& v, hipStream_t s, bool few_searches = true);
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s);
 bool line_search_tail_enabled(const BatchView& v);
 void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s);

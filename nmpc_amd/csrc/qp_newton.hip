@@ -472,7 +472,6 @@ NMPC_DEV void forward_pass(const BatchView& v, const Inst& I, bool live, int t) 
 #ifdef NMPC_SOLVE_STATS
 __device__ unsigned long long g_team_stats[16];   // per wave of a team: cycles, cycles waited, looks, sweeps
 #endif
-#ifndef NMPC_SINGLE_PRECISION
 // ------------------------------------------------------------------------
 // Team form of the bottom-up sweep: two wavefronts on two SIMDs of a CU work on
 // the same four instances.  Wave 0 factorises block after block exactly as
@@ -616,8 +615,9 @@ NMPC_DEV void factor_sweep(Shared& sh, const BatchView& v, const Inst& I, int st
             int failCol = -1;
             uint32_t ones = 0;
             real_t dd = 1.;
-            factor_columns<true>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
-            bool bad = active && ((k <= start && failCol >= 0) || ones == 0xffffffffu);
+            // (single precision takes roots and quotients plainly, as backward_pass does)
+            factor_columns<kDoublePrecision>(L, Ls, Ln, t, failCol, dd, ones, Seq12{});
+            bool bad = active && ((k <= start && failCol >= 0) || (kDoublePrecision && ones == 0xffffffffu));
 #ifdef NMPC_TEST_ALWAYS_REPEAT_BLOCKS     // test builds: give up half-way through every sweep
             bad = bad || k == N / 2;
 #endif
@@ -824,7 +824,6 @@ NMPC_DEV bool sweep(Shared& sh, const BatchView& v, const Inst& I, int start, bo
 }
 
 }  // namespace team
-#endif  // NMPC_SINGLE_PRECISION
 
 }  // namespace
 
@@ -906,7 +905,6 @@ void k_newton_solve(BatchView v) {
 #endif
 }
 
-#ifndef NMPC_SINGLE_PRECISION
 // The same solve with the first bottom-up sweep run by a team of two wavefronts
 // (namespace team); regularised second sweeps and sweeps the team gives up are
 // wave 0's alone, through the code of k_newton_solve; in the top-down
@@ -991,7 +989,6 @@ void k_newton_solve_team(BatchView v) {
         __syncthreads();            // both wavefronts are done with the counters before the next set resets them
     }
 }
-#endif  // NMPC_SINGLE_PRECISION
 
 // ------------------------------------------------------------------------
 // Instance list of a large grid's Newton solve: a counting sort of the running
@@ -1115,26 +1112,25 @@ BatchView solve_list_view(const BatchView& v, unsigned epoch, int part) {
 // whatever it is, in rounds if need be (with the bench workload's sixth of the
 // instances one round does up to 12 000 instances).  NMPC_NO_TEAM=1 keeps the
 // one-wavefront form.
-static bool team_wanted(const BatchView& v) {
-#ifdef NMPC_SINGLE_PRECISION
-    return false;
-#else
+// In single precision every search that goes on runs in k_line_search_tail, whose
+// workgroups of sixteen wavefronts find no room on a CU that holds a team (one
+// wavefront per SIMD, most of its registers): on warm control steps, with thousands of
+// searches in the other part, the teams cost more than they gain (4 096 x 100: cold
+// solve 5.23 -> 4.88 ms, warm step 5.59 -> 6.10 ms), hence few_searches.
+static bool team_wanted(const BatchView& v, bool few_searches) {
     static const bool off = getenv("NMPC_NO_TEAM") != nullptr;
     if (off || newton_solve_two_waves(v)) return false;
-    if (v.list) return v.listPart == 1;
+    if (v.list) return v.listPart == 1 && (kDoublePrecision || few_searches);
     return v.nb <= team::kMaxInstances;
-#endif
 }
 
-void launch_newton_solve(const BatchView& v, hipStream_t s) {
+void launch_newton_solve(const BatchView& v, hipStream_t s, bool few_searches) {
     const unsigned blocks = (unsigned)((v.nb + kGroupsPerWave - 1) / kGroupsPerWave);
-#ifndef NMPC_SINGLE_PRECISION
-    if (team_wanted(v)) {
+    if (team_wanted(v, few_searches)) {
         const unsigned most = team::kMaxInstances / kGroupsPerWave;
         hipLaunchKernelGGL(k_newton_solve_team, dim3(blocks < most ? blocks : most), dim3(team::kWaves * kWave), 0, s, v);
         return;
     }
-#endif
     if (newton_solve_two_waves(v)) hipLaunchKernelGGL(k_newton_solve<2>, dim3(blocks), dim3(kWave), 0, s, v);
     else hipLaunchKernelGGL(k_newton_solve<1>, dim3(blocks), dim3(kWave), 0, s, v);
 }
