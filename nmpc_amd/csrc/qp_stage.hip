@@ -1549,13 +1549,10 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_tail(BatchView v, 
 // The same continuation for horizons whose trial points do not fit the LDS of
 // k_line_search_tail: the trial loop of k_newton_step (one 256-thread workgroup
 // per search, trial points through global memory, row-ordered slope sums).
-__global__ __launch_bounds__(kStageThreads) void k_line_search_exact(BatchView v, int nextIt) {
-    extern __shared__ real_t lds_raw[];
-    const StageLds L = carve(lds_raw, v.N);
+// One search from the state in the instance's scalars to its end, by the whole workgroup.
+NMPC_DEV void exact_search(const BatchView& v, const Inst& I, const StageLds& L) {
     const int n = NX * v.N;
-    const int count = v.tailCount[kOpenList + nextIt - 2];
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        Inst I = instance(v, v.tailList[(kOpenList ? v.B : 0) + item]);
+    {
         Bisection bs{I.sc->lsMin, I.sc->lsMax, I.sc->lsMid, 0., I.sc->lsIter, I.sc->lsPhase, false};
         const real_t normal = I.sc->lsNormal;
         settle(bs);
@@ -1591,6 +1588,14 @@ __global__ __launch_bounds__(kStageThreads) void k_line_search_exact(BatchView v
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kStageThreads) void k_line_search_exact(BatchView v, int nextIt) {
+    extern __shared__ real_t lds_raw[];
+    const StageLds L = carve(lds_raw, v.N);
+    const int count = v.tailCount[kOpenList + nextIt - 2];
+    for (int item = blockIdx.x; item < count; item += gridDim.x)
+        exact_search(v, instance(v, v.tailList[(kOpenList ? v.B : 0) + item]), L);
 }
 
 // Commit and next Newton set-up of the instances k_line_search_tail finished.
@@ -1635,9 +1640,10 @@ __global__ __launch_bounds__(kTailThreads) void k_line_search_hessian(BatchView 
 // and goes through the same decisions, so the search state stays identical on all
 // of them without being exchanged (one barrier per round).  The sums are grouped
 // differently from k_line_search_fast's, which the rounding bound covers like any
-// other order.  Every thread returns whether the search is left open.
+// other order.  Every thread returns whether the search is left open (its state is
+// then in the instance's scalars).
 // lds: 5 (3 N + 12) + 4 * 16 + 32 values.
-NMPC_DEV bool team_search(const BatchView& v, const Inst& I, int b, int nextIt, real_t* lds) {
+NMPC_DEV bool team_search(const BatchView& v, const Inst& I, real_t* lds) {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
     const int N = v.N, n = NX * N, eEnd = NZ * N + NX, nBounded = 3 * N + NX;
     real_t* box = lds;                              // [5][nBounded]
@@ -1770,12 +1776,10 @@ NMPC_DEV bool team_search(const BatchView& v, const Inst& I, int b, int nextIt, 
     }
     if (tid == 0) {
         Scalars* sc = I.sc;
-        if (open) {
+        if (open) {             // the state the row-ordered continuation goes on from
             sc->lsMin = bs.aMin; sc->lsMax = bs.aMax; sc->lsMid = bs.aMid;
             sc->lsIter = bs.it;
             sc->lsPhase = bs.phase;
-            const int to = atomicAdd(&v.tailCount[8 + nextIt - 2], 1);
-            v.tailList[v.B + to] = b;
         } else {
             sc->alpha = bs.alpha;
             sc->lsIter = bs.it;
@@ -1788,8 +1792,10 @@ NMPC_DEV bool team_search(const BatchView& v, const Inst& I, int b, int nextIt, 
 // At most kFewSearches searches in the launch: each gets a workgroup of sixteen
 // wavefronts for the first attempt, the commit of the step and the next Newton
 // set-up with its Hessian block rows (what k_line_search_fast, _commit and _hessian
-// do in three launches).  A search the first attempt leaves open stays handed over:
-// k_line_search_tail, _commit and _hessian take it as they do when there are many.
+// do in three launches).  A search the first attempt leaves open goes on in the same
+// workgroup with trial points through global memory and row-ordered sums
+// (exact_search, what k_line_search_exact does), so none of a launch's few searches
+// is left for the kernels for many.
 __global__ __launch_bounds__(kStageThreads) void k_line_search_few(BatchView v, int nextIt) {
     extern __shared__ real_t lds_raw[];
     const int tid = threadIdx.x;
@@ -1799,7 +1805,7 @@ __global__ __launch_bounds__(kStageThreads) void k_line_search_few(BatchView v, 
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const int b = v.tailList[item];
         Inst I = instance(v, b);
-        if (team_search(v, I, b, nextIt, lds_raw)) continue;    // uniform
+        if (team_search(v, I, lds_raw)) exact_search(v, I, L);  // uniform
         const real_t alpha = I.sc->alpha;
         const int lsIter = I.sc->lsIter;
         for (int s = tid; s <= v.N; s += kStageThreads) L.chg[s] = 0;
@@ -1938,6 +1944,7 @@ void launch_line_search_tail(const BatchView& v, int next_it, hipStream_t s) {
     if (taken) {
         if (v.cfg) perinstance_wide::line_search_few(v, next_it, s);
         else batchwide_wide::line_search_few(v, next_it, s);
+        if (!v.list && v.nb <= 128) return;         // kFewSearches: a batch of that size never has more
     }
     if (wide_stage(v)) {
         if (v.cfg) perinstance_wide::line_search_tail(v, next_it, s, taken);
