@@ -78,6 +78,21 @@ struct Staging {        // grow-only device scratch for host-side inputs/outputs
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+// Small host-memory inputs (a measurement, a reference point, a wind vector of a few
+// instances) are copied into a slot of page-locked memory first and go to the device
+// from there: the caller's buffer is free when the call returns, so the call need not
+// wait for the stream, and a sequence of such calls (a control step through the
+// reference's interface is four of them) waits once, where results are read.
+// A slot is reused after kPinnedSlots further inputs, once the copy out of it is done.
+constexpr size_t kPinnedSlotBytes = 4096;
+constexpr unsigned kPinnedSlots = 64;
+struct PinnedRing {
+    char* base = nullptr;
+    hipEvent_t done[kPinnedSlots] = {};
+    unsigned next = 0;
+    bool failed = false;
+};
+
 // The entry point that allocates nothing (nmpc_batch_set_reference_from_waypoints_noalloc)
 // keeps its scratch in one fixed array per GPU, shared by the batches on that GPU
 // whatever their streams: a call records this event behind its last reader and
@@ -110,6 +125,7 @@ struct nmpc_batch {
     bool rti = false;
     std::vector<char> fresh;
     Staging in_refs, in_meas, in_wind, out_u, out_status, out_iters, scratch;
+    PinnedRing pinned;
     // nmpc_batch_init leaves the Jacobians C and residuals c logically zero; the
     // clear itself is postponed until something is about to read or partly
     // overwrite them, and dropped when every stage is linearised first.
@@ -213,10 +229,49 @@ int drain_timings(nmpc_batch* b) {
 
 // Device address of `bytes` of input: the caller's pointer when it already is
 // device memory, otherwise a staged copy.
-int stage_in(nmpc_batch* b, Staging& st, const void* src, size_t bytes, const void** dev) {
+// Host memory -> dst on the batch's stream.  *consumed: the source has been copied out of
+// (through page-locked memory) and the caller need not wait for the stream on its account.
+int copy_in(nmpc_batch* b, void* dst, const void* src, size_t bytes, bool* consumed) {
+    *consumed = false;
+    PinnedRing& r = b->pinned;
+    if (bytes <= kPinnedSlotBytes && !r.failed && !b->untimed) {
+        if (!r.base) {
+            if (hipHostMalloc((void**)&r.base, kPinnedSlotBytes * kPinnedSlots, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                r.base = nullptr;
+                r.failed = true;
+            }
+            for (unsigned i = 0; r.base && i < kPinnedSlots; i++)
+                if (hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    r.failed = true;            // (slots and events made so far are released with the batch)
+                    break;
+                }
+        }
+        if (r.base && !r.failed) {
+            const unsigned slot = r.next++ % kPinnedSlots;
+            HIP_TRY(hipEventSynchronize(r.done[slot]));     // the copy that last used the slot
+            char* at = r.base + (size_t)slot * kPinnedSlotBytes;
+            memcpy(at, src, bytes);
+            HIP_TRY(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipEventRecord(r.done[slot], b->stream));
+            *consumed = true;
+            return 0;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+    return 0;
+}
+
+// consumed (may be null): as copy_in's; always true for device memory.
+int stage_in(nmpc_batch* b, Staging& st, const void* src, size_t bytes, const void** dev,
+             bool* consumed = nullptr) {
+    if (consumed) *consumed = true;
     if (is_device_pointer(src)) { *dev = src; return 0; }
     TRY(st.reserve(bytes));
-    HIP_TRY(hipMemcpyAsync(st.ptr, src, bytes, hipMemcpyHostToDevice, b->stream));
+    bool done = false;
+    TRY(copy_in(b, st.ptr, src, bytes, &done));
+    if (consumed) *consumed = done;
     *dev = st.ptr;
     return 0;
 }
@@ -393,6 +448,8 @@ int nmpc_batch_destroy(nmpc_batch_t* b) {
     if (b->plant_next) (void)hipFree(b->plant_next);
     if (b->cfg) (void)hipFree(b->cfg);
     b->in_cfg.release();
+    for (auto ev : b->pinned.done) if (ev) (void)hipEventDestroy(ev);
+    if (b->pinned.base) (void)hipHostFree(b->pinned.base);
     if (b->arena) (void)hipFree(b->arena);
     if (b->side_stream) {
         (void)hipStreamSynchronize(b->side_stream);
@@ -547,9 +604,14 @@ int nmpc_batch_init(nmpc_batch_t* b) {
 int nmpc_batch_set_wind_velocity(nmpc_batch_t* b, const real_t* wind) {
     if (!b || !wind) return fail(NMPC_E_ARG, "nmpc_batch_set_wind_velocity: null argument");
     TRY(use_device(b));
-    HIP_TRY(hipMemcpyAsync(b->v.wind, wind, (size_t)b->v.B * 3 * sizeof(real_t),
-                           hipMemcpyDefault, b->stream));
-    if (!is_device_pointer(wind)) HIP_TRY(hipStreamSynchronize(b->stream));
+    const size_t bytes = (size_t)b->v.B * 3 * sizeof(real_t);
+    if (is_device_pointer(wind)) {
+        HIP_TRY(hipMemcpyAsync(b->v.wind, wind, bytes, hipMemcpyDeviceToDevice, b->stream));
+        return 0;
+    }
+    bool consumed = false;
+    TRY(copy_in(b, b->v.wind, wind, bytes, &consumed));
+    if (!consumed) HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
 
@@ -585,10 +647,10 @@ int nmpc_batch_set_reference_points(nmpc_batch_t* b, const real_t* refs, uint32_
         return fail(NMPC_E_ARG, "reference index %u beyond horizon %d", first + count - 1, b->v.N);
     TRY(use_device(b));
     const void* dev = nullptr;
-    const bool host = !is_device_pointer(refs);
-    TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(real_t), &dev));
+    bool consumed = true;
+    TRY(stage_in(b, b->in_refs, refs, (size_t)b->v.B * count * 16 * sizeof(real_t), &dev, &consumed));
     TRY(store_and_linearise(b, (const real_t*)dev, first, count));
-    if (host) HIP_TRY(hipStreamSynchronize(b->stream));   // caller may reuse its buffer
+    if (!consumed) HIP_TRY(hipStreamSynchronize(b->stream));  // caller may reuse its buffer
     return 0;
 }
 
@@ -765,8 +827,9 @@ int nmpc_batch_feedback_step(nmpc_batch_t* b, const real_t* measurement) {
     TRY(materialise_jacobians(b));
     b->zy_zero_pending = false;             // the opening step writes every z and y
     const void* dev = nullptr;
-    const bool host = !is_device_pointer(measurement);
-    TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(real_t), &dev));
+    bool consumed = true;
+    TRY(stage_in(b, b->in_meas, measurement, (size_t)b->v.B * 13 * sizeof(real_t), &dev, &consumed));
+    const bool host = !consumed;
     const real_t* dmeas = (const real_t*)dev;
     const BatchView& v = b->v;
     // the launches below follow each other with nothing between them
@@ -860,8 +923,9 @@ int nmpc_batch_update_horizon(nmpc_batch_t* b, const real_t* new_reference) {
     if (b->stage_zero_pending) TRY(materialise_stage_vectors(b));
     BatchView& v = b->v;
     const void* dev = nullptr;
-    const bool host = !is_device_pointer(new_reference);
-    TRY(stage_in(b, b->in_refs, new_reference, (size_t)v.B * 16 * sizeof(real_t), &dev));
+    bool consumed = true;
+    TRY(stage_in(b, b->in_refs, new_reference, (size_t)v.B * 16 * sizeof(real_t), &dev, &consumed));
+    const bool host = !consumed;
     // shift references, multipliers and stage records by one position
     v.xhead = (v.xhead + 1) % (v.N + 1);
     v.lhead = (v.lhead + 1) % v.N;
