@@ -1909,22 +1909,31 @@ NMPC_OTHER_COMPILATION(perinstance_wide)
 #undef NMPC_OTHER_COMPILATION
 
 namespace {
-// Workgroups of 1 024 threads for the kernels that follow the first Newton solve,
-// where a launch of few instances with long horizons leaves most of the chip idle
-// (the opening kernel has every instance of the batch to work on and stays as it
-// is).  NMPC_WIDE_STAGE=0 / 1: never / always.
+// A batch too small to fill the chip with 256-thread workgroups (it has no parts either).
+bool small_batch(const BatchView& v) { return !v.list && v.nb <= 256; }
+// Workgroups of 1 024 threads where a launch of few instances leaves most of the chip
+// idle: every stage kernel of a small batch, the opening one included, and from 200
+// stages on the kernels of the long part of a two-part iteration (the opening kernel
+// of a larger batch has every instance to work on and stays as it is).
+// NMPC_WIDE_STAGE=0 / 1: never / always.
 bool wide_stage(const BatchView& v) {
     static const int forced = getenv("NMPC_WIDE_STAGE") ? atoi(getenv("NMPC_WIDE_STAGE")) : -1;
     if (!kDoublePrecision) return false;
     // the long part of a two-part iteration, or a batch too small to have parts; a launch
     // over every instance of a larger batch is bound by throughput and slower this way
-    return forced >= 0 ? forced != 0 : (v.N >= 200 && (v.listPart == 1 || (!v.list && v.nb <= 256)));
+    return forced >= 0 ? forced != 0 : ((v.N >= 200 && v.listPart == 1) || small_batch(v));
 }
 }  // namespace
 
 void launch_qp_begin(const BatchView& v, const real_t* meas, hipStream_t s) {
-    if (v.cfg) perinstance::qp_begin(v, meas, s);
-    else batchwide::qp_begin(v, meas, s);
+    static const int forced = getenv("NMPC_WIDE_STAGE") ? atoi(getenv("NMPC_WIDE_STAGE")) : -1;
+    if (kDoublePrecision && (forced >= 0 ? forced != 0 : small_batch(v))) {
+        if (v.cfg) perinstance_wide::qp_begin(v, meas, s);
+        else batchwide_wide::qp_begin(v, meas, s);
+    } else {
+        if (v.cfg) perinstance::qp_begin(v, meas, s);
+        else batchwide::qp_begin(v, meas, s);
+    }
 }
 void launch_newton_step(const BatchView& v, int next_it, hipStream_t s) {
     if (wide_stage(v)) {
